@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: fp64 LU (getrf) GFLOP/s + solve latency on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one LU factorisation (blocked, partial pivoting) of one resident
+N x N matrix.  Every step factors its own pre-generated copy, so the timed
+region holds no fill and no device-to-device copy; inputs are synthetic
+(counter-based generator, lsx_fill_*_dev) and already in HBM.
+
+N=1 workload: BASELINE config #3's factorisation, 8192 x 8192 fp64 -- the size
+north_star quotes its targets on.  N>1: the same per-GPU flop count (weak
+scaling): n = 8192 * N^(1/3) rounded to the panel width, the trailing update
+sharded 1-D block-cyclic by columns with a panel broadcast per step
+(linalg_solver_amd/dist.py); N=8 gives config #4's 16384 x 16384.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"f64": 78.6, "f32": 157.3}  # dense MFMA TFLOP/s, MI355X (SURVEY section 6 / MICROARCH guide)
+HBM_PEAK_GBS = 8000.0
+
+
+def lu_flops(n: int) -> float:
+    return 2.0 / 3.0 * n ** 3
+
+
+def cpu_baseline(sample_n: int):
+    """The oracle's C restatement of the reference's row_reduce (1 core: the reference is
+    sequential by construction) on a bounded sample of the same generator."""
+    import numpy as np
+
+    from linalg_solver_amd import gen
+    from oracle import capi
+
+    A, b = gen.system(gen.U11, 1, sample_n)
+    aug = np.hstack([A, b[:, None]])
+    t0 = time.perf_counter()
+    red, piv, _ = capi.row_reduce(aug, want_steps=False)
+    dt = time.perf_counter() - t0
+    assert len(piv) == sample_n
+    flops = float(sample_n) ** 3  # forward 2/3 n^3 + back-elimination 1/3 n^3 (linalg.py:587-621)
+    out = {"value": flops / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/rowreduce_ref.c row_reduce([A|b]) at n={sample_n} u11 seed 1 "
+                     f"({dt:.1f} s, n^3 flops); reference Python itself: 0.013 GFLOP/s (BASELINE.md)"}
+    try:
+        import scipy.linalg as sl
+
+        n2 = 4096
+        A2 = gen.fill(gen.U11, 1, n2, n2)
+        t0 = time.perf_counter()
+        sl.lu_factor(A2, check_finite=False)
+        dt2 = time.perf_counter() - t0
+        out["lapack_dgetrf"] = {"value": lu_flops(n2) / dt2 / 1e9, "unit": "GFLOP/s", "n": n2,
+                                "cores": len(os.sched_getaffinity(0))}
+    except Exception as e:  # scipy is optional plumbing here
+        out["lapack_dgetrf"] = {"error": str(e)}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=0, help="matrix order (default: 8192 per-GPU-flop-equivalent)")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--nb", type=int, default=0)
+    ap.add_argument("--panel", type=int, default=-1)
+    ap.add_argument("--cpu-sample", type=int, default=3072)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip solve-latency / 4096 side measurements")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from linalg_solver_amd import gen
+    from linalg_solver_amd.device import DeviceSolver
+
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    dev = DeviceSolver(local_rank)
+    if args.nb:
+        dev.h.set_option("nb", args.nb)
+    if args.panel >= 0:
+        dev.h.set_option("panel", args.panel)
+    nb = dev.h.get_option("nb")
+    n = args.n or int(round(8192 * (world ** (1.0 / 3.0)) / 256.0)) * 256
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    total = args.steps + args.warmup
+    if world == 1:
+        mats = []
+        for s in range(total):
+            A = torch.empty(n, n, dtype=tdt, device="cuda")
+            dev.fill_(A, gen.U11, 1 + s)
+            mats.append(A)
+        ipiv = torch.empty(n, dtype=torch.int32, device="cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+        def step(i):
+            dev.getrf_(mats[i], ipiv, info)
+    else:
+        from linalg_solver_amd.dist import ShardedLU
+
+        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt)
+        shards = [slu.fill(gen.U11, 1 + s) for s in range(total)]
+
+        def step(i):
+            slu.factor_(shards[i])
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    dev.h.prof_reset()
+    dev.h.prof_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    dev.h.prof_enable(False)
+    prof = dev.h.prof_read()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if world == 1:
+        assert int(info.item()) == 0, "benchmark matrix was singular"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = lu_flops(n) * args.steps / dt / 1e9
+    g = prof["gemm"]
+    gemm_tflops = (g["flops"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
+    p = prof["panel"]
+    out = {
+        "metric": "fp64_lu_gflops" if args.dtype == "f64" else "fp32_lu_gflops",
+        "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{n}x{n} {args.dtype} LU with partial pivoting (getrf), u11 generator, resident in HBM",
+                   "n": n, "nb": nb, "panel_mode": dev.h.get_option("panel"),
+                   "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic columns x{world}, panel broadcast (RCCL)"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_sub_kernel (trailing update C -= L21*U12)",
+                     "achieved": gemm_tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                     "frac": gemm_tflops / PEAK[args.dtype], "traffic": None,
+                     "launches": g["launches"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
+                     "algorithmic_bytes": g["bytes"],
+                     "algorithmic_gbs": (g["bytes"] / (g["ms"] * 1e-3) / 1e9) if g["ms"] > 0 else 0.0},
+        "phases_ms_per_step": {k: v["ms"] / args.steps for k, v in prof.items()},
+        "panel_roofline": {"bound": "hbm", "achieved": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["ms"] > 0 else 0.0,
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ((p["bytes"] / (p["ms"] * 1e-3) / 1e9) / HBM_PEAK_GBS) if p["ms"] > 0 else 0.0,
+                           "algorithmic_bytes_per_step": p["bytes"] / args.steps},
+    }
+
+    if world == 1 and not args.no_extras:
+        # config #2: 4096 x 4096 LU + single right-hand-side solve latency
+        n2 = 4096
+        A2 = torch.empty(n2, n2, dtype=tdt, device="cuda")
+        ip2 = torch.empty(n2, dtype=torch.int32, device="cuda")
+        b2 = torch.empty(n2, 1, dtype=tdt, device="cuda")
+        reps = 3
+        ts = []
+        for r in range(reps + 1):
+            dev.fill_(A2, gen.U11, 1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.getrf_(A2, ip2, info)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        lu4096 = min(ts[1:])
+        ts = []
+        for r in range(reps + 1):
+            dev.fill_(b2, gen.U11, 1, col_off=gen.RHS_COL)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.getrs_(A2, ip2, b2)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out["config2_4096"] = {"lu_ms": lu4096 * 1e3, "lu_gflops": lu_flops(n2) / lu4096 / 1e9,
+                               "solve_1rhs_latency_ms": min(ts[1:]) * 1e3}
+        if args.dtype == "f64":
+            # config #3: inverse from the factors of the last benchmark matrix
+            LU = mats[-1]
+            inv = torch.empty(n, n, dtype=tdt, device="cuda")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.getri(LU, ipiv, inv)
+            torch.cuda.synchronize()
+            t_inv = time.perf_counter() - t0
+            out["config3_inverse"] = {"getri_ms": t_inv * 1e3, "lu_plus_inverse_ms": t_inv * 1e3 + ms_per_step,
+                                      "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9}
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

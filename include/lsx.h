@@ -1,0 +1,167 @@
+/* lsx.h -- C ABI of the MI355X-native dense LU / row-reduction library (liblsx.so)
+ *
+ * This is the drop-in boundary for the numeric core of koskja/linalg-solver's
+ *   Matrix.row_reduce()        linalg_solver/linalg.py:534-630
+ *   Matrix.find_preimage_of()  linalg_solver/linalg.py:632-680
+ *   Matrix.inverse()           linalg_solver/linalg.py:682-743
+ *   Matrix.determinant()       linalg_solver/linalg.py:183-207
+ *   Matrix.rank()              linalg_solver/linalg.py:745-747
+ * It takes the place of the reference's only native slot, the PyO3 module
+ * `linalg_helper` (linalg-helper/src/lib.rs:122-143, built by
+ * pyproject.toml:18-21): a shared library next to the Python package, entered
+ * through plain C symbols (ctypes; see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - Matrices are ROW-MAJOR (the reference stores list-of-rows), element (i,j)
+ *     at base[i*ld + j]; ld >= number of columns.
+ *   - Every call returns an int status: 0 = ok, <0 = bad argument / HIP error
+ *     (text via lsx_last_error()).  Numerical outcomes (singular matrix, rank)
+ *     are reported through out-parameters, never through the status, mirroring
+ *     the reference's "results are values, not exceptions" rule
+ *     (README.md:196-204, linalg.py:673,701,737).
+ *   - Caller owns every buffer it passes; the library never frees or keeps them.
+ *   - Host-buffer entry points copy to the device, compute there and copy back.
+ *     The *_dev entry points work on device pointers already resident in HBM and
+ *     are asynchronous on the handle's stream.
+ *   - One handle = one GPU = one host thread at a time.  Handles are independent.
+ *   - There is NO CPU fallback: without a usable gfx950 device lsx_create fails.
+ */
+#ifndef LSX_H
+#define LSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSX_VERSION 100
+
+typedef struct lsx_handle_s *lsx_handle_t;
+
+enum {
+    LSX_OK = 0,
+    LSX_ERR_ARG = -1,     /* invalid argument */
+    LSX_ERR_HIP = -2,     /* a HIP runtime call failed */
+    LSX_ERR_NODEVICE = -3,/* no gfx950 device / wrong architecture */
+    LSX_ERR_ALLOC = -4,   /* device allocation failed */
+    LSX_ERR_INTERNAL = -5 /* in-kernel protocol timeout or invariant violated */
+};
+
+/* input generators: counter-based, identical on host and device */
+enum { LSX_FILL_INT5 = 0, LSX_FILL_U11 = 1 };
+
+/* profiling buckets for lsx_prof_read */
+enum {
+    LSX_PROF_PANEL = 0,  /* panel factorisation kernels */
+    LSX_PROF_LASWP = 1,  /* row interchanges outside the panel */
+    LSX_PROF_TRSM = 2,   /* triangular inverse + U12 / block solves */
+    LSX_PROF_GEMM = 3,   /* trailing update C -= A*B (MFMA) */
+    LSX_PROF_OTHER = 4,
+    LSX_PROF_NBUCKETS = 5
+};
+
+/* ---- lifetime ---------------------------------------------------------- */
+int lsx_device_count(void);
+int lsx_create(lsx_handle_t *out, int device);
+int lsx_destroy(lsx_handle_t h);
+/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL restores the handle's own stream. */
+int lsx_set_stream(lsx_handle_t h, void *hip_stream);
+int lsx_synchronize(lsx_handle_t h);
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char *lsx_last_error(void);
+/* Tunables: "nb" (panel width), "panel" (0 = per-column launches, 1 = cooperative),
+ * "lookahead" (0/1).  Returns LSX_ERR_ARG for unknown keys. */
+int lsx_set_option(lsx_handle_t h, const char *key, int value);
+int lsx_get_option(lsx_handle_t h, const char *key, int *value);
+
+/* ---- host-buffer entry points (fp64) ------------------------------------ */
+/* In-place LU with partial pivoting, P*A = L*U, unit-lower L below the diagonal.
+ * ipiv[k] = 0-based row exchanged with row k at step k.  *info = 0, or k+1 for
+ * the first k whose pivot was exactly zero (factorisation continues). */
+int lsx_getrf_f64(lsx_handle_t h, int n, double *A, int lda, int32_t *ipiv, int *info);
+/* Solve A X = B from the factors; B (n x nrhs, row-major) is overwritten by X. */
+int lsx_getrs_f64(lsx_handle_t h, int n, int nrhs, const double *LU, int lda,
+                  const int32_t *ipiv, double *B, int ldb);
+/* Factor + solve; A is not modified.  Replaces row_reduce([A|B], bar_col=n) for
+ * square non-singular A (find_preimage_of, linalg.py:649-656). */
+int lsx_gesv_f64(lsx_handle_t h, int n, int nrhs, const double *A, int lda,
+                 double *B, int ldb, int *info, double *pivot_ratio);
+/* Inverse; replaces row_reduce([A|I], bar_col=n) (inverse, linalg.py:704-711).
+ * *info > 0: singular to working precision (caller returns NoSolution). */
+int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv, int ldi,
+                  int *info, double *pivot_ratio);
+/* det(A) = sign * mant * 2^exp2 with mant in [0.5,1) (or 0): never overflows.
+ * Replaces Matrix.determinant for numeric dense input (linalg.py:183-207). */
+int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, double *mant,
+                int64_t *exp2);
+/* General m x n reduced row echelon form over columns [0,bar_col) with the
+ * remaining columns carried along (row_reduce, linalg.py:534-630).  bar_col <= 0
+ * means n-1 (linalg.py:543).  pivots holds *rank pairs (row, col), 0-based.
+ * Pivot tolerance: |pivot| <= tol counts as zero; tol < 0 selects
+ * eps * max(m,n) * max|A|. */
+int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda,
+                 double *R, int ldr, int32_t *pivots, int *rank, double tol);
+
+/* ---- host-buffer entry points (fp32; BASELINE config 5) ------------------- */
+int lsx_getrf_f32(lsx_handle_t h, int n, float *A, int lda, int32_t *ipiv, int *info);
+int lsx_getrs_f32(lsx_handle_t h, int n, int nrhs, const float *LU, int lda,
+                  const int32_t *ipiv, float *B, int ldb);
+int lsx_gesv_f32(lsx_handle_t h, int n, int nrhs, const float *A, int lda, float *B, int ldb,
+                 int *info, double *pivot_ratio);
+
+/* ---- device-pointer entry points (asynchronous on the handle's stream) ---- */
+/* d_info: device int (may be NULL).  d_ipiv: device int32[n]. */
+int lsx_getrf_f64_dev(lsx_handle_t h, int n, double *dA, int lda, int32_t *d_ipiv, int *d_info);
+int lsx_getrs_f64_dev(lsx_handle_t h, int n, int nrhs, const double *dLU, int lda,
+                      const int32_t *d_ipiv, double *dB, int ldb);
+int lsx_getri_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
+                      double *dInv, int ldi);
+/* d_out[0]=sign, d_out[1]=mant, d_out[2]=(double)exp2 */
+int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
+                    double *d_out);
+int lsx_getrf_f32_dev(lsx_handle_t h, int n, float *dA, int lda, int32_t *d_ipiv, int *d_info);
+int lsx_getrs_f32_dev(lsx_handle_t h, int n, int nrhs, const float *dLU, int lda,
+                      const int32_t *d_ipiv, float *dB, int ldb);
+int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
+                     int32_t *d_pivots, int *d_rank, double tol);
+
+/* Building blocks used by the multi-GPU driver (1-D block-cyclic columns,
+ * SURVEY.md section 8e); all on device pointers, row-major. */
+/* Factor the m x jb panel at dP (rows are global rows row0..row0+m-1); writes
+ * d_ipiv[0..jb) as GLOBAL 0-based row indices and updates *d_info. */
+int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0,
+                      int32_t *d_ipiv, int *d_info);
+/* Apply the jb interchanges (k-th: row row0+k <-> d_ipiv[k]) to ncols columns of dA. */
+int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
+                      const int32_t *d_ipiv);
+/* dB (jb x ncols) <- inv(L11) * dB with L11 the unit-lower jb x jb block at dL. */
+int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int ldl, double *dB,
+                        int ldb);
+/* dC (m x n) -= dA (m x k) * dB (k x n) on the MFMA path. */
+int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
+                         const double *dB, int ldb, double *dC, int ldc);
+int lsx_gemm_sub_f32_dev(lsx_handle_t h, int m, int n, int k, const float *dA, int lda,
+                         const float *dB, int ldb, float *dC, int ldc);
+
+/* Deterministic synthetic inputs written straight into HBM:
+ * element (i,j) = f(splitmix64(seed*GOLDEN + (i+row_off)<<32 + (j+col_off))). */
+int lsx_fill_f64_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, double *dA, int lda,
+                     int row_off, int col_off);
+int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, float *dA, int lda,
+                     int row_off, int col_off);
+
+/* ---- measurement --------------------------------------------------------- */
+/* When enabled, every kernel launch of the buckets above is bracketed by HIP
+ * events on the launch stream; lsx_prof_read sums them (synchronises). */
+int lsx_prof_enable(lsx_handle_t h, int on);
+int lsx_prof_reset(lsx_handle_t h);
+int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, double *flops,
+                  double *bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSX_H */

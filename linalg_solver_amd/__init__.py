@@ -1,0 +1,13 @@
+"""MI355X-native dense LU / row reduction behind the linalg-solver `Matrix` surface.
+
+    from linalg_solver_amd import Matrix
+    Matrix([[2.0, 1.0], [1.0, 3.0]]).find_preimage_of([3.0, 5.0], log_steps=True)
+
+Layers: matrix.py (reference-compatible surface) -> dense.py (numpy buffers)
+-> _native.py (ctypes) -> liblsx.so (hand-written HIP for gfx950, csrc/).
+"""
+from . import dense, gen
+from ._native import Handle, LsxError, default_handle
+from .matrix import Matrix
+
+__all__ = ["Matrix", "Handle", "LsxError", "default_handle", "dense", "gen"]

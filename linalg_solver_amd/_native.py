@@ -1,0 +1,159 @@
+"""ctypes binding of liblsx.so (include/lsx.h).
+
+The library is the only compute path of this package: if it cannot be loaded,
+or no gfx950 device is visible, every entry point raises -- there is no CPU
+fallback (a silent one would make parity claims meaningless).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblsx.so")
+
+PROF_BUCKETS = {"panel": 0, "laswp": 1, "trsm": 2, "gemm": 3, "other": 4}
+FILL_INT5, FILL_U11 = 0, 1
+
+
+class LsxError(RuntimeError):
+    pass
+
+
+_lib = None
+_lock = threading.Lock()
+
+_dp, _fp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_float), C.POINTER(C.c_int32)
+_vp, _i, _u64 = C.c_void_p, C.c_int, C.c_uint64
+
+# name -> argtypes; every function returns int status except the two noted below.
+# Device-pointer entry points take raw addresses (c_void_p) so torch data_ptr() fits.
+_SIGS = {
+    "lsx_create": [C.POINTER(_vp), _i],
+    "lsx_destroy": [_vp],
+    "lsx_set_stream": [_vp, _vp],
+    "lsx_synchronize": [_vp],
+    "lsx_set_option": [_vp, C.c_char_p, _i],
+    "lsx_get_option": [_vp, C.c_char_p, C.POINTER(_i)],
+    "lsx_getrf_f64": [_vp, _i, _dp, _i, _ip, C.POINTER(_i)],
+    "lsx_getrs_f64": [_vp, _i, _i, _dp, _i, _ip, _dp, _i],
+    "lsx_gesv_f64": [_vp, _i, _i, _dp, _i, _dp, _i, C.POINTER(_i), _dp],
+    "lsx_getri_f64": [_vp, _i, _dp, _i, _dp, _i, C.POINTER(_i), _dp],
+    "lsx_det_f64": [_vp, _i, _dp, _i, _dp, _dp, C.POINTER(C.c_int64)],
+    "lsx_rref_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, _ip, C.POINTER(_i), C.c_double],
+    "lsx_getrf_f32": [_vp, _i, _fp, _i, _ip, C.POINTER(_i)],
+    "lsx_getrs_f32": [_vp, _i, _i, _fp, _i, _ip, _fp, _i],
+    "lsx_gesv_f32": [_vp, _i, _i, _fp, _i, _fp, _i, C.POINTER(_i), _dp],
+    "lsx_getrf_f64_dev": [_vp, _i, _vp, _i, _vp, _vp],
+    "lsx_getrs_f64_dev": [_vp, _i, _i, _vp, _i, _vp, _vp, _i],
+    "lsx_getri_f64_dev": [_vp, _i, _vp, _i, _vp, _vp, _i],
+    "lsx_det_f64_dev": [_vp, _i, _vp, _i, _vp, _vp],
+    "lsx_getrf_f32_dev": [_vp, _i, _vp, _i, _vp, _vp],
+    "lsx_getrs_f32_dev": [_vp, _i, _i, _vp, _i, _vp, _vp, _i],
+    "lsx_rref_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, C.c_double],
+    "lsx_panel_f64_dev": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "lsx_laswp_f64_dev": [_vp, _i, _vp, _i, _i, _i, _vp],
+    "lsx_trsm_lu_f64_dev": [_vp, _i, _i, _vp, _i, _vp, _i],
+    "lsx_gemm_sub_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
+    "lsx_gemm_sub_f32_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
+    "lsx_fill_f64_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
+    "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
+    "lsx_prof_enable": [_vp, _i],
+    "lsx_prof_reset": [_vp],
+    "lsx_prof_read": [_vp, _i, _dp, C.POINTER(C.c_longlong), _dp, _dp],
+}
+EXPORTS = sorted(list(_SIGS) + ["lsx_device_count", "lsx_last_error"])
+
+
+def load():
+    """dlopen liblsx.so (no device is touched yet)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise LsxError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` (hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+            L = C.CDLL(LIB_PATH)
+            for name, args in _SIGS.items():
+                fn = getattr(L, name)
+                fn.restype = C.c_int
+                fn.argtypes = args
+            L.lsx_device_count.restype = C.c_int
+            L.lsx_device_count.argtypes = []
+            L.lsx_last_error.restype = C.c_char_p
+            L.lsx_last_error.argtypes = []
+            _lib = L
+    return _lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().lsx_last_error().decode("utf-8", "replace")
+        raise LsxError(f"{what or 'liblsx'} failed (status {status}): {msg}")
+
+
+class Handle:
+    """One GPU, one stream, growable device workspaces (lsx_create / lsx_destroy)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        self._h = _vp()
+        check(self.lib.lsx_create(C.byref(self._h), int(device)), "lsx_create")
+        self.device = device
+
+    @property
+    def ptr(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.lsx_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: str, value: int):
+        check(self.lib.lsx_set_option(self._h, key.encode(), int(value)), f"set_option({key})")
+
+    def get_option(self, key: str) -> int:
+        v = _i(0)
+        check(self.lib.lsx_get_option(self._h, key.encode(), C.byref(v)), f"get_option({key})")
+        return v.value
+
+    def set_stream(self, stream_ptr: int):
+        check(self.lib.lsx_set_stream(self._h, _vp(stream_ptr)), "lsx_set_stream")
+
+    def synchronize(self):
+        check(self.lib.lsx_synchronize(self._h), "lsx_synchronize")
+
+    # measurement
+    def prof_enable(self, on: bool = True):
+        check(self.lib.lsx_prof_enable(self._h, 1 if on else 0))
+
+    def prof_reset(self):
+        check(self.lib.lsx_prof_reset(self._h))
+
+    def prof_read(self):
+        out = {}
+        for name, b in PROF_BUCKETS.items():
+            ms, fl, by = C.c_double(0), C.c_double(0), C.c_double(0)
+            n = C.c_longlong(0)
+            check(self.lib.lsx_prof_read(self._h, b, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[name] = {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+        return out
+
+
+_default = {}
+
+
+def default_handle(device: int = 0) -> Handle:
+    h = _default.get(device)
+    if h is None:
+        h = _default[device] = Handle(device)
+    return h

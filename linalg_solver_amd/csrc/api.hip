@@ -1,0 +1,596 @@
+// C-ABI of liblsx.so (see include/lsx.h) and the host-side drivers of the
+// blocked algorithms.  All device work is enqueued on the handle's stream with
+// no host synchronisation inside a factorisation or solve: pivots, info and
+// rank stay on the device, so a whole getrf is graph-capturable.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace lsx {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static int grow(void **p, size_t *have, size_t need) {
+    if (need <= *have) return LSX_OK;
+    if (*p) {
+        LSX_HIP(hipFree(*p));
+        *p = nullptr;
+        *have = 0;
+    }
+    need = (need + (1u << 20) - 1) & ~((size_t)(1u << 20) - 1);
+    hipError_t e = hipMalloc(p, need);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", need, hipGetErrorString(e));
+        *p = nullptr;
+        return LSX_ERR_ALLOC;
+    }
+    *have = need;
+    return LSX_OK;
+}
+
+int ensure_ws(lsx_handle_t h, size_t bytes) { return grow(&h->ws, &h->ws_bytes, bytes); }
+
+static int ensure_scratch(lsx_handle_t h, size_t bytes) {
+    // growing frees the old block: make sure nothing queued still uses it
+    if (bytes > h->scratch_bytes) LSX_HIP(hipStreamSynchronize(h->stream));
+    return grow(&h->scratch, &h->scratch_bytes, bytes);
+}
+
+ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : h(h_) {
+    Prof &p = h->prof;
+    if (!p.on) return;
+    ProfEvent ev;
+    ev.bucket = bucket;
+    for (hipEvent_t *e : {&ev.a, &ev.b}) {
+        if (!p.pool.empty()) {
+            *e = p.pool.back();
+            p.pool.pop_back();
+        } else if (hipEventCreate(e) != hipSuccess) {
+            return;
+        }
+    }
+    (void)hipEventRecord(ev.a, h->stream);
+    p.pending.push_back(ev);
+    idx = (int)p.pending.size() - 1;
+    p.launches[bucket] += 1;
+    p.flops[bucket] += flops;
+    p.bytes[bucket] += bytes;
+}
+
+ProfScope::~ProfScope() {
+    if (idx >= 0) (void)hipEventRecord(h->prof.pending[idx].b, h->stream);
+}
+
+// simple bump carving of a device block
+struct Carver {
+    char *base;
+    size_t off = 0;
+    explicit Carver(void *b) : base((char *)b) {}
+    template <typename U>
+    U *take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        U *p = (U *)(base + off);
+        off += count * sizeof(U);
+        return p;
+    }
+};
+
+static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// ---------------------------------------------------------------- blocked LU driver
+template <typename T>
+static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info) {
+    LSX_ARG(n >= 0 && lda >= n && A && d_ipiv);
+    if (n == 0) return LSX_OK;
+    const int nb = h->nb;
+    // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) + 4096));
+    const size_t tinv_elems = (size_t)((nb + 63) / 64) * 64 * 64;
+    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
+    T *Tinv = (T *)h->ws2;
+    if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
+    for (int k = 0; k < n; k += nb) {
+        const int jb = (n - k < nb) ? n - k : nb;
+        T *Akk = A + (size_t)k * lda + k;
+        LSX_TRY(launch_panel<T>(h, n - k, jb, Akk, lda, k, d_ipiv + k, d_info));
+        LSX_TRY(launch_laswp<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        const int rest = n - k - jb;
+        if (rest > 0) {
+            T *A12 = A + (size_t)k * lda + k + jb;
+            LSX_TRY(launch_laswp<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
+            LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Tinv, A12, lda));
+            LSX_TRY(launch_gemm_sub<T>(h, rest, rest, jb, A + (size_t)(k + jb) * lda + k, lda, A12, lda,
+                                       A + (size_t)(k + jb) * lda + k + jb, lda));
+        }
+    }
+    return LSX_OK;
+}
+
+// X <- U^-1 L^-1 X for X already row-permuted (n x nrhs)
+template <typename T>
+static int lu_solve_permuted(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *X, int ldx) {
+    const int sb = 128;
+    const size_t blk = (size_t)((n + 63) / 64) * 64 * 64;
+    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(blk * sizeof(T))));
+    T *TinvL = (T *)h->ws2;
+    T *TinvU = (T *)((char *)h->ws2 + pad256(blk * sizeof(T)));
+    LSX_TRY(launch_trtri<T>(h, 1, n, LU, lda, TinvL));
+    LSX_TRY(launch_trtri<T>(h, 0, n, LU, lda, TinvU));
+    for (int kb = 0; kb < n; kb += sb) {  // forward: L y = P b   (linalg.py:587-596)
+        const int jb = (n - kb < sb) ? n - kb : sb;
+        LSX_TRY(launch_trsm_block<T>(h, 1, jb, nrhs, LU + (size_t)kb * lda + kb, lda,
+                                     TinvL + (size_t)(kb / 64) * 4096, X + (size_t)kb * ldx, ldx));
+        const int below = n - kb - jb;
+        if (below > 0)
+            LSX_TRY(launch_gemm_sub<T>(h, below, nrhs, jb, LU + (size_t)(kb + jb) * lda + kb, lda,
+                                       X + (size_t)kb * ldx, ldx, X + (size_t)(kb + jb) * ldx, ldx));
+    }
+    const int last = ((n - 1) / sb) * sb;
+    for (int kb = last; kb >= 0; kb -= sb) {  // backward: U x = y   (linalg.py:611-621)
+        const int jb = (n - kb < sb) ? n - kb : sb;
+        LSX_TRY(launch_trsm_block<T>(h, 0, jb, nrhs, LU + (size_t)kb * lda + kb, lda,
+                                     TinvU + (size_t)(kb / 64) * 4096, X + (size_t)kb * ldx, ldx));
+        if (kb > 0)
+            LSX_TRY(launch_gemm_sub<T>(h, kb, nrhs, jb, LU + kb, lda, X + (size_t)kb * ldx, ldx, X, ldx));
+    }
+    return LSX_OK;
+}
+
+template <typename T>
+static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, const int32_t *d_ipiv,
+                     T *B, int ldb) {
+    LSX_ARG(n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs && LU && d_ipiv && B);
+    if (n == 0 || nrhs == 0) return LSX_OK;
+    // perm + a copy of B for the row gather
+    LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n) + pad256(sizeof(T) * (size_t)n * nrhs)));
+    int32_t *perm = (int32_t *)h->ws3;
+    T *Bc = (T *)((char *)h->ws3 + pad256(sizeof(int32_t) * n));
+    LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
+    LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nrhs));
+    LSX_TRY(launch_gather_rows<T>(h, n, nrhs, perm, Bc, nrhs, B, ldb));
+    return lu_solve_permuted<T>(h, n, nrhs, LU, lda, B, ldb);
+}
+
+template <typename T>
+static int getri_dev(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, T *Inv,
+                     int ldi) {
+    LSX_ARG(n >= 0 && lda >= n && ldi >= n && LU && d_ipiv && Inv);
+    if (n == 0) return LSX_OK;
+    LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n)));
+    int32_t *perm = (int32_t *)h->ws3;
+    LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
+    LSX_TRY(launch_set_identity_perm<T>(h, n, perm, Inv, ldi));  // P * I
+    return lu_solve_permuted<T>(h, n, n, LU, lda, Inv, ldi);
+}
+
+// ---------------------------------------------------------------- host-buffer wrappers
+template <typename T>
+static int h2d(lsx_handle_t h, int m, int n, const T *src, int lds, T *dst, int ldd) {
+    LSX_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * sizeof(T), src, (size_t)lds * sizeof(T),
+                             (size_t)n * sizeof(T), m, hipMemcpyHostToDevice, h->stream));
+    return LSX_OK;
+}
+template <typename T>
+static int d2h(lsx_handle_t h, int m, int n, const T *src, int lds, T *dst, int ldd) {
+    LSX_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * sizeof(T), src, (size_t)lds * sizeof(T),
+                             (size_t)n * sizeof(T), m, hipMemcpyDeviceToHost, h->stream));
+    return LSX_OK;
+}
+
+static int ld_for(int n) { return (n + 15) & ~15; }  // device leading dimension: 128-B rows (fp64)
+
+template <typename T>
+static int getrf_host(lsx_handle_t h, int n, T *A, int lda, int32_t *ipiv, int *info) {
+    LSX_ARG(h && n >= 0 && lda >= n && (n == 0 || (A && ipiv)));
+    if (info) *info = 0;
+    if (n == 0) return LSX_OK;
+    const int ld = ld_for(n);
+    LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 512));
+    Carver c(h->ws);
+    T *dA = c.take<T>((size_t)n * ld);
+    int32_t *dp = c.take<int32_t>(n);
+    int *dinfo = c.take<int>(1);
+    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(d2h<T>(h, n, n, dA, ld, A, lda));
+    LSX_HIP(hipMemcpyAsync(ipiv, dp, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
+    int hinfo = 0;
+    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (info) *info = hinfo;
+    return LSX_OK;
+}
+
+template <typename T>
+static int getrs_host(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, const int32_t *ipiv,
+                      T *B, int ldb) {
+    LSX_ARG(h && n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs);
+    if (n == 0 || nrhs == 0) return LSX_OK;
+    LSX_ARG(LU && ipiv && B);
+    const int ld = ld_for(n), ldx = ld_for(nrhs);
+    LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)n * ld) + pad256(sizeof(T) * (size_t)n * ldx) +
+                             pad256(sizeof(int32_t) * n) + 512));
+    Carver c(h->ws);
+    T *dA = c.take<T>((size_t)n * ld);
+    T *dB = c.take<T>((size_t)n * ldx);
+    int32_t *dp = c.take<int32_t>(n);
+    LSX_TRY(h2d<T>(h, n, n, LU, lda, dA, ld));
+    LSX_TRY(h2d<T>(h, n, nrhs, B, ldb, dB, ldx));
+    LSX_HIP(hipMemcpyAsync(dp, ipiv, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
+    LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
+    LSX_TRY(d2h<T>(h, n, nrhs, dB, ldx, B, ldb));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+
+template <typename T>
+static int gesv_host(lsx_handle_t h, int n, int nrhs, const T *A, int lda, T *B, int ldb, int *info,
+                     double *pivot_ratio) {
+    LSX_ARG(h && n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs);
+    if (info) *info = 0;
+    if (pivot_ratio) *pivot_ratio = 1.0;
+    if (n == 0) return LSX_OK;
+    LSX_ARG(A && (nrhs == 0 || B));
+    const int ld = ld_for(n), ldx = ld_for(nrhs > 0 ? nrhs : 1);
+    LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)n * ld) + pad256(sizeof(T) * (size_t)n * ldx) +
+                             pad256(sizeof(int32_t) * n) + 1024));
+    Carver c(h->ws);
+    T *dA = c.take<T>((size_t)n * ld);
+    T *dB = c.take<T>((size_t)n * ldx);
+    int32_t *dp = c.take<int32_t>(n);
+    int *dinfo = c.take<int>(1);
+    double *dprobe = c.take<double>(2);
+    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
+    if (nrhs > 0) LSX_TRY(h2d<T>(h, n, nrhs, B, ldb, dB, ldx));
+    LSX_TRY(launch_amax<T>(h, n, n, dA, ld, dprobe));
+    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
+    int hinfo = 0;
+    double probe[2] = {0, 0};
+    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipMemcpyAsync(probe, dprobe, sizeof(probe), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (info) *info = hinfo;
+    if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
+    if (hinfo != 0 || nrhs == 0) return LSX_OK;  // singular: B is left untouched
+    LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
+    LSX_TRY(d2h<T>(h, n, nrhs, dB, ldx, B, ldb));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+
+}  // namespace lsx
+
+using namespace lsx;
+
+// ================================================================== extern "C"
+extern "C" {
+
+const char *lsx_last_error(void) { return g_err; }
+
+int lsx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int lsx_create(lsx_handle_t *out, int device) {
+    if (!out) { set_error("lsx_create: null out"); return LSX_ERR_ARG; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("no HIP device visible; liblsx has no CPU fallback");
+        return LSX_ERR_NODEVICE;
+    }
+    LSX_ARG(device >= 0 && device < n);
+    hipDeviceProp_t prop;
+    LSX_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; liblsx is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return LSX_ERR_NODEVICE;
+    }
+    LSX_HIP(hipSetDevice(device));
+    lsx_handle_t h = new lsx_handle_s();
+    h->device = device;
+    h->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete h;
+        return LSX_ERR_HIP;
+    }
+    h->stream = h->own_stream;
+    int r = grow(&h->scratch, &h->scratch_bytes, 1 << 20);
+    if (r != LSX_OK) { (void)hipStreamDestroy(h->own_stream); delete h; return r; }
+    *out = h;
+    return LSX_OK;
+}
+
+int lsx_destroy(lsx_handle_t h) {
+    if (!h) return LSX_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &ev : h->prof.pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    for (auto &e : h->prof.pool) (void)hipEventDestroy(e);
+    if (h->ws) (void)hipFree(h->ws);
+    if (h->ws2) (void)hipFree(h->ws2);
+    if (h->ws3) (void)hipFree(h->ws3);
+    if (h->scratch) (void)hipFree(h->scratch);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return LSX_OK;
+}
+
+int lsx_set_stream(lsx_handle_t h, void *hip_stream) {
+    LSX_ARG(h);
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    return LSX_OK;
+}
+
+int lsx_synchronize(lsx_handle_t h) {
+    LSX_ARG(h);
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+
+int lsx_set_option(lsx_handle_t h, const char *key, int value) {
+    LSX_ARG(h && key);
+    if (!strcmp(key, "nb")) {
+        LSX_ARG(value >= 16 && value <= 256 && value % 16 == 0);
+        h->nb = value;
+    } else if (!strcmp(key, "panel")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->panel_mode = value;
+    } else if (!strcmp(key, "lookahead")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->lookahead = value;
+    } else {
+        set_error("unknown option '%s'", key);
+        return LSX_ERR_ARG;
+    }
+    return LSX_OK;
+}
+
+int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
+    LSX_ARG(h && key && value);
+    if (!strcmp(key, "nb")) *value = h->nb;
+    else if (!strcmp(key, "panel")) *value = h->panel_mode;
+    else if (!strcmp(key, "lookahead")) *value = h->lookahead;
+    else if (!strcmp(key, "num_cu")) *value = h->num_cu;
+    else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
+    return LSX_OK;
+}
+
+// ---- fp64 host
+int lsx_getrf_f64(lsx_handle_t h, int n, double *A, int lda, int32_t *ipiv, int *info) {
+    return getrf_host<double>(h, n, A, lda, ipiv, info);
+}
+int lsx_getrs_f64(lsx_handle_t h, int n, int nrhs, const double *LU, int lda, const int32_t *ipiv,
+                  double *B, int ldb) {
+    return getrs_host<double>(h, n, nrhs, LU, lda, ipiv, B, ldb);
+}
+int lsx_gesv_f64(lsx_handle_t h, int n, int nrhs, const double *A, int lda, double *B, int ldb,
+                 int *info, double *pivot_ratio) {
+    return gesv_host<double>(h, n, nrhs, A, lda, B, ldb, info, pivot_ratio);
+}
+int lsx_getrf_f32(lsx_handle_t h, int n, float *A, int lda, int32_t *ipiv, int *info) {
+    return getrf_host<float>(h, n, A, lda, ipiv, info);
+}
+int lsx_getrs_f32(lsx_handle_t h, int n, int nrhs, const float *LU, int lda, const int32_t *ipiv,
+                  float *B, int ldb) {
+    return getrs_host<float>(h, n, nrhs, LU, lda, ipiv, B, ldb);
+}
+int lsx_gesv_f32(lsx_handle_t h, int n, int nrhs, const float *A, int lda, float *B, int ldb,
+                 int *info, double *pivot_ratio) {
+    return gesv_host<float>(h, n, nrhs, A, lda, B, ldb, info, pivot_ratio);
+}
+
+int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv, int ldi, int *info,
+                  double *pivot_ratio) {
+    LSX_ARG(h && n >= 0 && lda >= n && ldi >= n);
+    if (info) *info = 0;
+    if (pivot_ratio) *pivot_ratio = 1.0;
+    if (n == 0) return LSX_OK;
+    LSX_ARG(A && Ainv);
+    const int ld = ld_for(n);
+    LSX_TRY(ensure_ws(h, 2 * pad256(sizeof(double) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
+    Carver c(h->ws);
+    double *dA = c.take<double>((size_t)n * ld);
+    double *dI = c.take<double>((size_t)n * ld);
+    int32_t *dp = c.take<int32_t>(n);
+    int *dinfo = c.take<int>(1);
+    double *dprobe = c.take<double>(2);
+    LSX_TRY(h2d<double>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(launch_amax<double>(h, n, n, dA, ld, dprobe));
+    LSX_TRY(getrf_dev<double>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(launch_diag_minabs<double>(h, n, dA, ld, dprobe));
+    int hinfo = 0;
+    double probe[2] = {0, 0};
+    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipMemcpyAsync(probe, dprobe, sizeof(probe), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (info) *info = hinfo;
+    if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
+    if (hinfo != 0) return LSX_OK;  // exactly singular: caller reports NoSolution (linalg.py:737)
+    LSX_TRY(getri_dev<double>(h, n, dA, ld, dp, dI, ld));
+    LSX_TRY(d2h<double>(h, n, n, dI, ld, Ainv, ldi));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+
+int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, double *mant,
+                int64_t *exp2) {
+    LSX_ARG(h && n >= 0 && lda >= n && sign && mant && exp2);
+    if (n == 0) { *sign = 1; *mant = 0.5; *exp2 = 1; return LSX_OK; }  // det([]) = 1 (linalg.py:197-199)
+    LSX_ARG(A);
+    const int ld = ld_for(n);
+    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
+    Carver c(h->ws);
+    double *dA = c.take<double>((size_t)n * ld);
+    int32_t *dp = c.take<int32_t>(n);
+    int *dinfo = c.take<int>(1);
+    double *dout = c.take<double>(3);
+    LSX_TRY(h2d<double>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(getrf_dev<double>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(launch_det<double>(h, n, dA, ld, dp, dout));
+    double out[3];
+    LSX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    *sign = out[0]; *mant = out[1]; *exp2 = (int64_t)out[2];
+    return LSX_OK;
+}
+
+int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
+                 int ldr, int32_t *pivots, int *rank, double tol) {
+    LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && rank);
+    const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
+    LSX_ARG(bar <= n);
+    const int ld = ld_for(n);
+    const int np = m < n ? m : n;
+    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)m * ld) + pad256(sizeof(int32_t) * 2 * np) + 512));
+    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096));
+    Carver c(h->ws);
+    double *dR = c.take<double>((size_t)m * ld);
+    int32_t *dp = c.take<int32_t>(2 * (size_t)np);
+    int *drank = c.take<int>(1);
+    LSX_TRY(h2d<double>(h, m, n, A, lda, dR, ld));
+    LSX_TRY(launch_rref<double>(h, m, n, bar, dR, ld, dp, drank, tol));
+    LSX_TRY(d2h<double>(h, m, n, dR, ld, R, ldr));
+    int hr = 0;
+    LSX_HIP(hipMemcpyAsync(&hr, drank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    *rank = hr;
+    if (hr > 0) LSX_HIP(hipMemcpy(pivots, dp, sizeof(int32_t) * 2 * hr, hipMemcpyDeviceToHost));
+    return LSX_OK;
+}
+
+// ---- device-pointer entry points
+int lsx_getrf_f64_dev(lsx_handle_t h, int n, double *dA, int lda, int32_t *d_ipiv, int *d_info) {
+    LSX_ARG(h);
+    return getrf_dev<double>(h, n, dA, lda, d_ipiv, d_info);
+}
+int lsx_getrf_f32_dev(lsx_handle_t h, int n, float *dA, int lda, int32_t *d_ipiv, int *d_info) {
+    LSX_ARG(h);
+    return getrf_dev<float>(h, n, dA, lda, d_ipiv, d_info);
+}
+int lsx_getrs_f64_dev(lsx_handle_t h, int n, int nrhs, const double *dLU, int lda,
+                      const int32_t *d_ipiv, double *dB, int ldb) {
+    LSX_ARG(h);
+    return getrs_dev<double>(h, n, nrhs, dLU, lda, d_ipiv, dB, ldb);
+}
+int lsx_getrs_f32_dev(lsx_handle_t h, int n, int nrhs, const float *dLU, int lda,
+                      const int32_t *d_ipiv, float *dB, int ldb) {
+    LSX_ARG(h);
+    return getrs_dev<float>(h, n, nrhs, dLU, lda, d_ipiv, dB, ldb);
+}
+int lsx_getri_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
+                      double *dInv, int ldi) {
+    LSX_ARG(h);
+    return getri_dev<double>(h, n, dLU, lda, d_ipiv, dInv, ldi);
+}
+int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
+                    double *d_out) {
+    LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
+    return launch_det<double>(h, n, dLU, lda, d_ipiv, d_out);
+}
+int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
+                     int32_t *d_pivots, int *d_rank, double tol) {
+    LSX_ARG(h && m >= 1 && n >= 1 && ldr >= n && dR && d_pivots);
+    const int bar = bar_col > 0 ? bar_col : n - 1;
+    LSX_ARG(bar <= n);
+    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096));
+    return launch_rref<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol);
+}
+
+int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,
+                      int *d_info) {
+    LSX_ARG(h && m >= jb && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + 4096));
+    return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
+}
+int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
+                      const int32_t *d_ipiv) {
+    LSX_ARG(h && dA && d_ipiv && jb >= 0 && jb <= 256);
+    return launch_laswp<double>(h, ncols, dA, lda, row0, jb, d_ipiv);
+}
+int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int ldl, double *dB,
+                        int ldb) {
+    LSX_ARG(h && dL && dB && jb >= 1 && jb <= 256);
+    const size_t tinv = (size_t)((jb + 63) / 64) * 4096 * sizeof(double);
+    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv)));
+    LSX_TRY(launch_trtri<double>(h, 1, jb, dL, ldl, (double *)h->ws2));
+    return launch_trsm_block<double>(h, 1, jb, ncols, dL, ldl, (const double *)h->ws2, dB, ldb);
+}
+int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
+                         const double *dB, int ldb, double *dC, int ldc) {
+    LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
+    return launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
+}
+int lsx_gemm_sub_f32_dev(lsx_handle_t h, int m, int n, int k, const float *dA, int lda,
+                         const float *dB, int ldb, float *dC, int ldc) {
+    LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
+    return launch_gemm_sub<float>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
+}
+
+int lsx_fill_f64_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, double *dA, int lda,
+                     int row_off, int col_off) {
+    LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
+    return launch_fill<double>(h, kind, seed, m, n, dA, lda, row_off, col_off);
+}
+int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, float *dA, int lda,
+                     int row_off, int col_off) {
+    LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
+    return launch_fill<float>(h, kind, seed, m, n, dA, lda, row_off, col_off);
+}
+
+// ---- measurement
+int lsx_prof_enable(lsx_handle_t h, int on) {
+    LSX_ARG(h);
+    h->prof.on = on != 0;
+    return LSX_OK;
+}
+
+static int prof_drain(lsx_handle_t h) {
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    Prof &p = h->prof;
+    for (auto &ev : p.pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) p.ms[ev.bucket] += ms;
+        p.pool.push_back(ev.a);
+        p.pool.push_back(ev.b);
+    }
+    p.pending.clear();
+    return LSX_OK;
+}
+
+int lsx_prof_reset(lsx_handle_t h) {
+    LSX_ARG(h);
+    LSX_TRY(prof_drain(h));
+    for (int b = 0; b < LSX_PROF_NBUCKETS; ++b) {
+        h->prof.ms[b] = 0; h->prof.launches[b] = 0; h->prof.flops[b] = 0; h->prof.bytes[b] = 0;
+    }
+    return LSX_OK;
+}
+
+int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, double *flops,
+                  double *bytes) {
+    LSX_ARG(h && bucket >= 0 && bucket < LSX_PROF_NBUCKETS);
+    LSX_TRY(prof_drain(h));
+    if (ms) *ms = h->prof.ms[bucket];
+    if (launches) *launches = h->prof.launches[bucket];
+    if (flops) *flops = h->prof.flops[bucket];
+    if (bytes) *bytes = h->prof.bytes[bucket];
+    return LSX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// Internal declarations shared by the HIP sources of liblsx.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lsx.h"
+
+namespace lsx {
+
+void set_error(const char *fmt, ...);
+
+#define LSX_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            lsx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                     \
+            return LSX_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define LSX_TRY(call)              \
+    do {                           \
+        int r_ = (call);           \
+        if (r_ != LSX_OK) return r_; \
+    } while (0)
+
+#define LSX_ARG(cond)                                                     \
+    do {                                                                  \
+        if (!(cond)) {                                                    \
+            lsx::set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+            return LSX_ERR_ARG;                                           \
+        }                                                                 \
+    } while (0)
+
+struct ProfEvent {
+    hipEvent_t a, b;
+    int bucket;
+};
+
+struct Prof {
+    bool on = false;
+    std::vector<ProfEvent> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[LSX_PROF_NBUCKETS] = {0};
+    long long launches[LSX_PROF_NBUCKETS] = {0};
+    double flops[LSX_PROF_NBUCKETS] = {0};
+    double bytes[LSX_PROF_NBUCKETS] = {0};
+};
+
+}  // namespace lsx
+
+struct lsx_handle_s {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // stream in use (own or borrowed)
+    // tunables
+    int nb = 128;        // panel width
+    int panel_mode = 0;  // 0 = per-column launches, 1 = cooperative kernel
+    int lookahead = 0;
+    int num_cu = 256;
+    // persistent device workspace (grown on demand, never shrunk)
+    void *ws = nullptr;      // staging of caller matrices (host-buffer entry points)
+    size_t ws_bytes = 0;
+    void *ws2 = nullptr;     // triangular block inverses
+    size_t ws2_bytes = 0;
+    void *ws3 = nullptr;     // permutation vector + right-hand-side copy
+    size_t ws3_bytes = 0;
+    // small fixed device scratch: pivot search partials, flags, info words
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    lsx::Prof prof;
+};
+
+namespace lsx {
+
+int ensure_ws(lsx_handle_t h, size_t bytes);
+
+// RAII-less profiling bracket: call begin() before a launch group, end() after.
+struct ProfScope {
+    lsx_handle_t h;
+    int idx = -1;
+    ProfScope(lsx_handle_t h_, int bucket, double flops = 0, double bytes = 0);
+    ~ProfScope();
+};
+
+template <typename T>
+struct Real;
+template <>
+struct Real<double> {
+    static constexpr double eps = 2.220446049250313e-16;
+};
+template <>
+struct Real<float> {
+    static constexpr float eps = 1.1920929e-07f;
+};
+
+// ---- kernel launchers (one per .hip file section); all asynchronous on h->stream ----
+template <typename T>
+int launch_fill(lsx_handle_t h, int kind, uint64_t seed, int m, int n, T *A, int lda, int row_off,
+                int col_off);
+template <typename T>
+int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
+                    T *C, int ldc);
+template <typename T>
+int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
+                 int *d_info);
+template <typename T>
+int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, const int32_t *d_ipiv);
+// Tinv (ceil(jb/64) blocks of 64x64) <- inverses of the 64x64 diagonal blocks of the
+// unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.
+template <typename T>
+int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv);
+// B (jb x ncols) <- inv(Tm) * B in place; Tinv = inverses of Tm's 64x64 diagonal blocks.
+template <typename T>
+int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm, int ldt,
+                      const T *Tinv, T *B, int ldb);
+int launch_ipiv_to_perm(lsx_handle_t h, int n, const int32_t *d_ipiv, int32_t *d_perm);
+template <typename T>
+int launch_gather_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_perm, const T *S, int lds,
+                       T *D, int ldd);
+template <typename T>
+int launch_set_identity_perm(lsx_handle_t h, int n, const int32_t *d_perm, T *X, int ldx);
+template <typename T>
+int launch_apply_ipiv_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_ipiv, T *B, int ldb);
+template <typename T>
+int launch_det(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, double *d_out);
+template <typename T>
+int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots,
+                int *d_rank, double tol);
+// d_out[0] = max|A_ij| ; d_out[1] = min_k |LU_kk|
+template <typename T>
+int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out);
+template <typename T>
+int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out);
+template <typename T>
+int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd);
+
+}  // namespace lsx

@@ -1,0 +1,252 @@
+// Trailing-submatrix update  C (m x n) -= A (m x k) * B (k x n)  on the MFMA pipe.
+//
+// Takes the place of the reference's elimination loop
+// (linalg_solver/linalg.py:587-596: row_k -= f * row_p for every row below the
+// pivot, one pivot at a time) applied for a whole block of `k` pivots at once:
+// A = L21 (the multipliers f of k pivot columns), B = U12 (the k pivot rows).
+//
+// gfx950 design
+//   - v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32, 64-lane wavefronts.
+//   - workgroup = 4 waves, macro tile 128 x 128, each wave a 64 x 64 quadrant
+//     held as 4 x 4 MFMA accumulators (128 VGPRs in fp64); 2 workgroups per CU.
+//   - the accumulators are initialised FROM C (one HBM read) and A is negated
+//     on its way into LDS, so the k-loop computes C - A*B in place and C is
+//     written exactly once: algorithmic HBM traffic = 2 * sizeof(T) * m * n.
+//   - A / B k-slabs (BK = 16) are staged global -> registers -> LDS with one
+//     register set in flight across the MFMA block (guide T14), two LDS
+//     buffers, one barrier per slab.  LDS rows are padded so the 32-lane halves
+//     of a ds_read_b64 land on disjoint banks.
+//   - within a wave the 4 N-tiles interleave columns (column = 4*(lane&15)+t),
+//     so each lane owns 4 consecutive C elements per row and C moves in 16/32-B
+//     pieces per lane, 512 B contiguous per row per wave.
+//   - 1-D grid with an XCD-aware, grouped tile order: blocks that share an XCD
+//     (blockIdx % 8) walk a compact band of tiles, so L21 / U12 slabs are
+//     served from that XCD's L2 instead of HBM.
+#include "common.h"
+
+namespace lsx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct Mfma;
+template <>
+struct Mfma<double> {
+    typedef d4 acc_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    // C/D element r of a lane sits at row (lane>>4) + 4*r, column lane&15
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma<float> {
+    typedef f4 acc_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // f32 form: row 4*(lane>>4) + r, column lane&15
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) banks
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(int M, int N, int K,
+                                                          const T *__restrict__ A, int lda,
+                                                          const T *__restrict__ B, int ldb,
+                                                          T *__restrict__ C, int ldc, int tiles_m,
+                                                          int tiles_n) {
+    typedef typename Mfma<T>::acc_t acc_t;
+    __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
+    __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
+
+    // ---- XCD-aware grouped tile order
+    const int nwg = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    const int group_id = bid / per_group;
+    const int first_m = group_id * GROUP;
+    const int gsize = min(tiles_m - first_m, GROUP);
+    const int tile_m = first_m + (bid % per_group) % gsize;
+    const int tile_n = (bid % per_group) / gsize;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lc = lane & 15, lq = lane >> 4;
+
+    // ---- accumulators <- C.  Lane owns columns wn + 4*lc + t (t = N-tile index).
+    acc_t acc[4][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
+            const int col = n0 + wn + 4 * lc;
+            const T *p = C + (size_t)row * ldc + col;
+            T v[4] = {0, 0, 0, 0};
+            if (row < M) {
+                if (col + 3 < N) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = p[t];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (col + t < N) v[t] = p[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[s][t][r] = v[t];
+        }
+
+    // ---- staging maps
+    // A slab 128 x 16: thread -> row (tid>>3) + 32*i, k-pair (tid&7)*2
+    // B slab 16 x 128: thread -> k (tid>>6) + 4*i, column pair (tid&63)*2
+    const int a_row = tid >> 3, a_k = (tid & 7) * 2;
+    const int b_k = tid >> 6, b_n = (tid & 63) * 2;
+    T ra[4][2], rb[4][2];
+
+    auto load_slab = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + a_row + 32 * i;
+            const int kk = k0 + a_k;
+            const T *p = A + (size_t)row * lda + kk;
+            ra[i][0] = (row < M && kk < K) ? p[0] : T(0);
+            ra[i][1] = (row < M && kk + 1 < K) ? p[1] : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = k0 + b_k + 4 * i;
+            const int col = n0 + b_n;
+            const T *p = B + (size_t)kk * ldb + col;
+            rb[i][0] = (kk < K && col < N) ? p[0] : T(0);
+            rb[i][1] = (kk < K && col + 1 < N) ? p[1] : T(0);
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            As[buf][a_k][a_row + 32 * i] = -ra[i][0];
+            As[buf][a_k + 1][a_row + 32 * i] = -ra[i][1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // column n (within the tile) -> wave half h = n>>6, c = (n&63)>>2, t = n&3 -> 64*h + 16*t + c
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int n = b_n + e;
+                const int np = (n & 64) + 16 * (n & 3) + ((n & 63) >> 2);
+                Bs[buf][b_k + 4 * i][np] = rb[i][e];
+            }
+        }
+    };
+
+    const int nslab = (K + BK - 1) / BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    for (int kt = 0; kt < nslab; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nslab) load_slab((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            T a[4], b[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = As[buf][kk + lq][wm + 16 * s + lc];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = Bs[buf][kk + lq][wn + 16 * t + lc];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[s][t] = Mfma<T>::mma(a[s], b[t], acc[s][t]);
+        }
+        if (kt + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- C <- accumulators
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
+            const int col = n0 + wn + 4 * lc;
+            T *p = C + (size_t)row * ldc + col;
+            if (row < M) {
+                if (col + 3 < N) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) p[t] = acc[s][t][r];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (col + t < N) p[t] = acc[s][t][r];
+                }
+            }
+        }
+}
+
+// Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
+// one thread per C element, A row and B column streamed from L2.
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_sub_skinny_kernel(int M, int N, int K,
+                                                              const T *__restrict__ A, int lda,
+                                                              const T *__restrict__ B, int ldb,
+                                                              T *__restrict__ C, int ldc) {
+    // one wave per row of C: lanes split K, shuffle-reduce, lane j<N writes column j
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T *a = A + (size_t)row * lda;
+    for (int j0 = 0; j0 < N; j0 += 8) {
+        T part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = lane; k < K; k += 64) {
+            const T av = a[k];
+            const T *b = B + (size_t)k * ldb + j0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j0 + j < N) part[j] += av * b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T v = part[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && j0 + j < N) C[(size_t)row * ldc + j0 + j] -= v;
+        }
+    }
+}
+
+template <typename T>
+int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
+                    T *C, int ldc) {
+    if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_GEMM, 2.0 * m * n * (double)k, 2.0 * sizeof(T) * m * (double)n);
+    if (n < 16) {
+        hipLaunchKernelGGL(gemm_sub_skinny_kernel<T>, dim3((m + 3) / 4), dim3(256), 0, h->stream, m,
+                           n, k, A, lda, B, ldb, C, ldc);
+    } else {
+        const int tm = (m + BM - 1) / BM, tn = (n + BN - 1) / BN;
+        hipLaunchKernelGGL(gemm_sub_kernel<T>, dim3(tm * tn), dim3(256), 0, h->stream, m, n, k, A,
+                           lda, B, ldb, C, ldc, tm, tn);
+    }
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+template int launch_gemm_sub<double>(lsx_handle_t, int, int, int, const double *, int,
+                                     const double *, int, double *, int);
+template int launch_gemm_sub<float>(lsx_handle_t, int, int, int, const float *, int, const float *,
+                                    int, float *, int);
+
+}  // namespace lsx

@@ -1,0 +1,580 @@
+// Supporting kernels: deterministic fills, row interchanges, triangular block
+// inverses + block solves, determinant reduction, permutation helpers.
+#include "common.h"
+
+namespace lsx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct MfmaS;
+template <>
+struct MfmaS<double> {
+    typedef d4 acc_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct MfmaS<float> {
+    typedef f4 acc_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// ------------------------------------------------------------------ fill
+__host__ __device__ inline uint64_t splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename T>
+__global__ void fill_kernel(int kind, uint64_t seed, int m, int n, T *A, int lda, int row_off,
+                            int col_off) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n || i >= m) return;
+    const uint64_t h = splitmix64(seed * 0x9E3779B97F4A7C15ull + ((uint64_t)(uint32_t)(i + row_off) << 32) +
+                                  (uint64_t)(uint32_t)(j + col_off));
+    double v;
+    if (kind == LSX_FILL_INT5)
+        v = (double)(int)(h % 11ull) - 5.0;  // integers -5..5 (random_matrix.py:104)
+    else
+        v = (double)(h >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;  // uniform [-1,1)
+    A[(size_t)i * lda + j] = (T)v;
+}
+
+template <typename T>
+int launch_fill(lsx_handle_t h, int kind, uint64_t seed, int m, int n, T *A, int lda, int row_off,
+                int col_off) {
+    if (m <= 0 || n <= 0) return LSX_OK;
+    hipLaunchKernelGGL(fill_kernel<T>, dim3((n + 255) / 256, m), dim3(256), 0, h->stream, kind, seed,
+                       m, n, A, lda, row_off, col_off);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ laswp
+// Applies the jb sequential interchanges (row0+k <-> ipiv[k]) to a column
+// chunk as ONE gather: every affected destination row finds its source by
+// walking the interchange list backwards (O(jb) per row, all rows in
+// parallel), the chunk's source rows are staged in LDS, then written out.
+// HBM traffic: each affected row segment read once and written once.
+// (Reference: the O(1) list swap at linalg.py:552.)
+template <typename T, int CW>
+__global__ __launch_bounds__(256) void laswp_kernel(int ncols, T *__restrict__ A, int lda, int row0,
+                                                    int jb, const int32_t *__restrict__ ipiv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *s_piv = (int *)smem;             // jb
+    int *s_dst = s_piv + 256;             // 2*jb
+    int *s_src = s_dst + 512;             // 2*jb
+    T *tile = (T *)(smem + (256 + 512 + 512) * sizeof(int));  // [2*jb][CW]
+    const int tid = threadIdx.x;
+    for (int k = tid; k < jb; k += 256) s_piv[k] = ipiv[k];
+    __syncthreads();
+    const int nd = 2 * jb;
+    for (int d = tid; d < nd; d += 256) {
+        const int dst = d < jb ? row0 + d : s_piv[d - jb];
+        int x = dst;
+        for (int k = jb - 1; k >= 0; --k) {
+            const int t = row0 + k, p = s_piv[k];
+            x = (x == t) ? p : ((x == p) ? t : x);
+        }
+        // rows listed twice (d >= jb duplicates) keep only their first listing
+        bool dup = false;
+        if (d >= jb) {
+            if (dst < row0 + jb) dup = true;  // already covered by the top block
+            for (int e = 0; e < d - jb && !dup; ++e) dup = (s_piv[e] == dst);
+        }
+        s_dst[d] = (dup || x == dst) ? -1 : dst;
+        s_src[d] = x;
+    }
+    __syncthreads();
+    const int c0 = blockIdx.x * CW;
+    const int tc = tid % CW, tr = tid / CW;
+    constexpr int RP = 256 / CW;  // rows per pass
+    const bool cok = c0 + tc < ncols;
+    for (int d = tr; d < nd; d += RP)
+        if (s_dst[d] >= 0 && cok) tile[d * CW + tc] = A[(size_t)s_src[d] * lda + c0 + tc];
+    __syncthreads();
+    for (int d = tr; d < nd; d += RP)
+        if (s_dst[d] >= 0 && cok) A[(size_t)s_dst[d] * lda + c0 + tc] = tile[d * CW + tc];
+}
+
+template <typename T>
+int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, const int32_t *d_ipiv) {
+    if (ncols <= 0 || jb <= 0) return LSX_OK;
+    if (jb > 256) {
+        set_error("laswp: jb %d > 256", jb);
+        return LSX_ERR_ARG;
+    }
+    constexpr int CW = 32;
+    ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * jb * (double)ncols);
+    const size_t shm = (256 + 512 + 512) * sizeof(int) + (size_t)2 * jb * CW * sizeof(T);
+    if (shm > 48 * 1024)
+        LSX_HIP(hipFuncSetAttribute((const void *)laswp_kernel<T, CW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((laswp_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), shm, h->stream,
+                       ncols, A, lda, row0, jb, d_ipiv);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ triangular 64-block inverse
+// One workgroup inverts one 64 x 64 diagonal block of a unit-lower (lower=1) or
+// non-unit upper (lower=0) triangle: 16 x 16 blocks by substitution, then two
+// levels of 2x2 block merges  X21 = -X22 * (T21 * X11)  on the MFMA pipe,
+// everything LDS-resident.  Rows/columns past jb are treated as identity.
+constexpr int TB = 64;        // diagonal block edge
+constexpr int TLD = TB + 2;   // padded LDS leading dimension
+
+template <typename T>
+__device__ void lds_gemm_tile(int M, int N, int K, const T *A, int lda, const T *B, int ldb, T *D,
+                              int ldd, T alpha, int wave, int nwaves, int lane) {
+    typedef typename MfmaS<T>::acc_t acc_t;
+    const int lc = lane & 15, lq = lane >> 4;
+    const int tn = N / 16, nt = (M / 16) * tn;
+    for (int tile = wave; tile < nt; tile += nwaves) {
+        const int i0 = (tile / tn) * 16, j0 = (tile % tn) * 16;
+        acc_t acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 4)
+            acc = MfmaS<T>::mma(A[(i0 + lc) * lda + k0 + lq], B[(k0 + lq) * ldb + j0 + lc], acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) D[(i0 + MfmaS<T>::crow(lane, r)) * ldd + j0 + lc] = alpha * acc[r];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T *__restrict__ Tm,
+                                                      int ldt, T *__restrict__ Tinv) {
+    __shared__ T X[TB * TLD];   // triangle in, inverse out
+    __shared__ T W[32 * TLD];   // merge temporary
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * TB;
+    // load (identity outside the matrix / outside the triangle)
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int i = e / TB, j = e % TB;
+        const int gi = b0 + i, gj = b0 + j;
+        T v = (i == j) ? T(1) : T(0);
+        if (gi < jb && gj < jb) {
+            if (lower) {
+                if (j < i) v = Tm[(size_t)gi * ldt + gj];
+            } else {
+                if (j >= i) v = Tm[(size_t)gi * ldt + gj];
+            }
+        }
+        X[i * TLD + j] = v;
+    }
+    __syncthreads();
+    // 16 x 16 diagonal blocks: thread (blk, col) solves one column by substitution
+    if (tid < 64) {
+        const int blk = tid >> 4, c = tid & 15, o = blk * 16;
+        T x[16];
+        if (lower) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                T s = (i == c) ? T(1) : T(0);
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (t < i) s -= X[(o + i) * TLD + o + t] * ((t >= c) ? x[t] : T(0));
+                x[i] = (i >= c) ? s : T(0);  // unit diagonal
+            }
+        } else {
+#pragma unroll
+            for (int ii = 0; ii < 16; ++ii) {
+                const int i = 15 - ii;
+                T s = (i == c) ? T(1) : T(0);
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (t > i) s -= X[(o + i) * TLD + o + t] * ((t <= c) ? x[t] : T(0));
+                x[i] = (i <= c) ? s / X[(o + i) * TLD + o + i] : T(0);
+            }
+        }
+        // single wave, lockstep: every lane's LDS reads above are issued before these writes
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[(o + i) * TLD + o + c] = x[i];
+    }
+    __syncthreads();
+    // merges: s = 16 -> 32 -> 64.  lower: X21 = -X22 * (L21 * X11); upper: X12 = -X11 * (U12 * X22)
+    for (int s = 16; s < TB; s *= 2) {
+        for (int o = 0; o < TB; o += 2 * s) {
+            const T *P11 = X + o * TLD + o;
+            const T *P22 = X + (o + s) * TLD + o + s;
+            T *Off = lower ? X + (o + s) * TLD + o : X + o * TLD + o + s;
+            if (lower)
+                lds_gemm_tile<T>(s, s, s, Off, TLD, P11, TLD, W, TLD, T(1), wave, 4, lane);
+            else
+                lds_gemm_tile<T>(s, s, s, Off, TLD, P22, TLD, W, TLD, T(1), wave, 4, lane);
+            __syncthreads();
+            if (lower)
+                lds_gemm_tile<T>(s, s, s, P22, TLD, W, TLD, Off, TLD, T(-1), wave, 4, lane);
+            else
+                lds_gemm_tile<T>(s, s, s, P11, TLD, W, TLD, Off, TLD, T(-1), wave, 4, lane);
+            __syncthreads();
+        }
+    }
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int i = e / TB, j = e % TB;
+        Tinv[(size_t)blockIdx.x * TB * TB + e] = X[i * TLD + j];
+    }
+}
+
+template <typename T>
+int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv) {
+    if (jb <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_TRSM);
+    hipLaunchKernelGGL(trtri64_kernel<T>, dim3((jb + TB - 1) / TB), dim3(256), 0, h->stream, lower,
+                       jb, Tm, ldt, Tinv);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ block triangular solve
+// B (jb x ncols) <- inv(Tri) * B for the jb x jb triangle at Tm, given the
+// inverses of its 64 x 64 diagonal blocks (Tinv).  Each workgroup owns a chunk
+// of CWT columns for ALL jb rows, so the block substitution needs no grid sync:
+//   lower: for b = 0..nb-1:  B_b -= sum_{t<b} T_bt B_t ;  B_b = Tinv_b B_b
+//   upper: for b = nb-1..0:  B_b -= sum_{t>b} T_bt B_t ;  B_b = Tinv_b B_b
+// This is the U12 = L11^-1 A12 step of the blocked LU and the diagonal step of
+// the blocked forward / backward solves (reference: the normalise + eliminate
+// loops of linalg.py:569-596 and 611-621 restricted to the pivot block rows).
+constexpr int CWT = 32;
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_block_kernel(int lower, int jb, int ncols,
+                                                         const T *__restrict__ Tm, int ldt,
+                                                         const T *__restrict__ Tinv,
+                                                         T *__restrict__ B, int ldb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nblk = (jb + TB - 1) / TB;
+    const int BLD = CWT + 2;
+    T *Bs = (T *)smem;                       // [nblk*TB][BLD]
+    T *Ts = Bs + (size_t)nblk * TB * BLD;    // [TB][TLD] staged T_bt or Tinv_b
+    T *Ws = Ts + TB * TLD;                   // [TB][BLD] product temporary
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * CWT;
+    for (int e = tid; e < nblk * TB * CWT; e += 256) {
+        const int i = e / CWT, j = e % CWT;
+        Bs[i * BLD + j] = (i < jb && c0 + j < ncols) ? B[(size_t)i * ldb + c0 + j] : T(0);
+    }
+    __syncthreads();
+    for (int bb = 0; bb < nblk; ++bb) {
+        const int b = lower ? bb : nblk - 1 - bb;
+        for (int tt = 0; tt < bb; ++tt) {
+            const int t = lower ? tt : nblk - 1 - tt;
+            // stage T_bt (64 x 64)
+            for (int e = tid; e < TB * TB; e += 256) {
+                const int i = e / TB, j = e % TB;
+                const int gi = b * TB + i, gj = t * TB + j;
+                Ts[i * TLD + j] = (gi < jb && gj < jb) ? Tm[(size_t)gi * ldt + gj] : T(0);
+            }
+            __syncthreads();
+            lds_gemm_tile<T>(TB, CWT, TB, Ts, TLD, Bs + (size_t)t * TB * BLD, BLD, Ws, BLD, T(1), wave,
+                             4, lane);
+            __syncthreads();
+            for (int e = tid; e < TB * CWT; e += 256) {
+                const int i = e / CWT, j = e % CWT;
+                Bs[(b * TB + i) * BLD + j] -= Ws[i * BLD + j];
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int i = e / TB, j = e % TB;
+            Ts[i * TLD + j] = Tinv[(size_t)b * TB * TB + e];
+        }
+        __syncthreads();
+        lds_gemm_tile<T>(TB, CWT, TB, Ts, TLD, Bs + (size_t)b * TB * BLD, BLD, Ws, BLD, T(1), wave, 4,
+                         lane);
+        __syncthreads();
+        for (int e = tid; e < TB * CWT; e += 256) {
+            const int i = e / CWT, j = e % CWT;
+            Bs[(b * TB + i) * BLD + j] = Ws[i * BLD + j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nblk * TB * CWT; e += 256) {
+        const int i = e / CWT, j = e % CWT;
+        if (i < jb && c0 + j < ncols) B[(size_t)i * ldb + c0 + j] = Bs[i * BLD + j];
+    }
+}
+
+template <typename T>
+int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm, int ldt,
+                      const T *Tinv, T *B, int ldb) {
+    if (jb <= 0 || ncols <= 0) return LSX_OK;
+    const int nblk = (jb + TB - 1) / TB;
+    const size_t shm = ((size_t)nblk * TB * (CWT + 2) + TB * TLD + TB * (CWT + 2)) * sizeof(T);
+    if (shm > 160 * 1024) {
+        set_error("trsm_block: jb %d too large for LDS", jb);
+        return LSX_ERR_ARG;
+    }
+    ProfScope ps(h, LSX_PROF_TRSM, (double)jb * jb * ncols);
+    if (shm > 48 * 1024)
+        LSX_HIP(hipFuncSetAttribute((const void *)trsm_block_kernel<T>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL(trsm_block_kernel<T>, dim3((ncols + CWT - 1) / CWT), dim3(256), shm, h->stream,
+                       lower, jb, ncols, Tm, ldt, Tinv, B, ldb);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ permutation helpers
+// Apply all n interchanges of a factorisation to the rows of B (n x ncols):
+// forward order, as LAPACK's laswp.  One thread per column walks the list;
+// rows it touches are L2-resident for the narrow right-hand sides this serves.
+template <typename T>
+__global__ void apply_ipiv_rows_kernel(int n, int ncols, const int32_t *__restrict__ ipiv, T *B,
+                                       int ldb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    for (int k = 0; k < n; ++k) {
+        const int p = ipiv[k];
+        if (p != k) {
+            const T a = B[(size_t)k * ldb + c], b = B[(size_t)p * ldb + c];
+            B[(size_t)k * ldb + c] = b;
+            B[(size_t)p * ldb + c] = a;
+        }
+    }
+}
+
+template <typename T>
+int launch_apply_ipiv_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_ipiv, T *B, int ldb) {
+    if (n <= 0 || ncols <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_OTHER);
+    hipLaunchKernelGGL(apply_ipiv_rows_kernel<T>, dim3((ncols + 63) / 64), dim3(64), 0, h->stream, n,
+                       ncols, d_ipiv, B, ldb);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// perm[i] = original row that ends at position i after all n interchanges.
+// Each thread walks the interchange list backwards from its own position
+// (the list is broadcast from LDS / L2), so the conversion is O(n) deep and
+// n-wide instead of an n-step serial chain.
+__global__ __launch_bounds__(256) void ipiv_to_perm_kernel(int n, const int32_t *__restrict__ ipiv,
+                                                           int32_t *__restrict__ perm) {
+    __shared__ int s_piv[2048];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int x = i;
+    for (int base = ((n - 1) / 2048) * 2048; base >= 0; base -= 2048) {
+        const int cnt = min(2048, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cnt; k += 256) s_piv[k] = ipiv[base + k];
+        __syncthreads();
+        for (int k = cnt - 1; k >= 0; --k) {
+            const int t = base + k, p = s_piv[k];
+            x = (x == t) ? p : ((x == p) ? t : x);
+        }
+    }
+    if (i < n) perm[i] = x;
+}
+
+// D[i][:] = S[perm[i]][:]
+template <typename T>
+__global__ void gather_rows_kernel(int n, int ncols, const int32_t *__restrict__ perm,
+                                   const T *__restrict__ S, int lds, T *__restrict__ D, int ldd) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < ncols) D[(size_t)i * ldd + j] = S[(size_t)perm[i] * lds + j];
+}
+
+int launch_ipiv_to_perm(lsx_handle_t h, int n, const int32_t *d_ipiv, int32_t *d_perm) {
+    if (n <= 0) return LSX_OK;
+    hipLaunchKernelGGL(ipiv_to_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_ipiv,
+                       d_perm);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+template <typename T>
+int launch_gather_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_perm, const T *S, int lds,
+                       T *D, int ldd) {
+    if (n <= 0 || ncols <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_OTHER);
+    hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((ncols + 255) / 256, n), dim3(256), 0, h->stream,
+                       n, ncols, d_perm, S, lds, D, ldd);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// X (n x n) <- P (the row-permuted identity): X[i][perm[i]] = 1.  This is the
+// right-hand side of the inverse, [A|I] at linalg.py:704-706, after pivoting.
+template <typename T>
+__global__ void set_perm_identity_kernel(int n, const int32_t *__restrict__ perm, T *X, int ldx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= n) return;
+    X[(size_t)i * ldx + j] = (perm[i] == j) ? T(1) : T(0);
+}
+
+template <typename T>
+int launch_set_identity_perm(lsx_handle_t h, int n, const int32_t *perm, T *X, int ldx) {
+    if (n <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_OTHER);
+    hipLaunchKernelGGL(set_perm_identity_kernel<T>, dim3((n + 255) / 256, n), dim3(256), 0, h->stream,
+                       n, perm, X, ldx);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ determinant
+// det = sign * mant * 2^exp with mant in [0.5, 1): product of diag(U) kept as a
+// (mantissa, exponent) pair so 8192 factors neither overflow nor underflow;
+// sign also flips once per actual interchange.  One workgroup, tree reduction.
+template <typename T>
+__global__ __launch_bounds__(256) void det_kernel(int n, const T *__restrict__ LU, int lda,
+                                                  const int32_t *__restrict__ ipiv, double *out) {
+    __shared__ double s_m[256];
+    __shared__ long long s_e[256];
+    __shared__ int s_neg[256];
+    __shared__ int s_zero[256];
+    const int tid = threadIdx.x;
+    double m = 1.0;
+    long long e = 0;
+    int neg = 0, zero = 0;
+    for (int k = tid; k < n; k += 256) {
+        double d = (double)LU[(size_t)k * lda + k];
+        if (ipiv[k] != k) neg ^= 1;
+        if (d == 0.0) { zero = 1; continue; }
+        if (d < 0) { neg ^= 1; d = -d; }
+        int ex;
+        const double f = frexp(d, &ex);
+        m *= f;
+        e += ex;
+        int ex2;
+        m = frexp(m, &ex2);
+        e += ex2;
+    }
+    s_m[tid] = m; s_e[tid] = e; s_neg[tid] = neg; s_zero[tid] = zero;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            int ex;
+            s_m[tid] = frexp(s_m[tid] * s_m[tid + s], &ex);
+            s_e[tid] += s_e[tid + s] + ex;
+            s_neg[tid] ^= s_neg[tid + s];
+            s_zero[tid] |= s_zero[tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (s_zero[0]) {
+            out[0] = 0.0; out[1] = 0.0; out[2] = 0.0;
+        } else {
+            out[0] = s_neg[0] ? -1.0 : 1.0;
+            out[1] = s_m[0];
+            out[2] = (double)s_e[0];
+        }
+    }
+}
+
+template <typename T>
+int launch_det(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, double *d_out) {
+    ProfScope ps(h, LSX_PROF_OTHER);
+    hipLaunchKernelGGL(det_kernel<T>, dim3(1), dim3(256), 0, h->stream, n, LU, lda, d_ipiv, d_out);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ conditioning probes
+// out[0] = max |A_ij| over an m x n block (atomic max on the bit pattern of a
+// non-negative double; out[0] must be zeroed first).
+template <typename T>
+__global__ __launch_bounds__(256) void amax_kernel(int m, int n, const T *__restrict__ A, int lda,
+                                                   double *out) {
+    __shared__ double s[256];
+    double v = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < (size_t)m * n;
+         e += (size_t)gridDim.x * 256) {
+        const double a = fabs((double)A[(e / n) * (size_t)lda + (e % n)]);
+        if (a > v) v = a;
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) s[threadIdx.x] = fmax(s[threadIdx.x], s[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        atomicMax((unsigned long long *)out, (unsigned long long)__double_as_longlong(s[0]));
+}
+
+// out[1] = min_k |LU_kk| (one workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void diag_minabs_kernel(int n, const T *__restrict__ LU, int lda,
+                                                          double *out) {
+    __shared__ double s[256];
+    double v = INFINITY;
+    for (int k = threadIdx.x; k < n; k += 256) {
+        const double a = fabs((double)LU[(size_t)k * lda + k]);
+        if (!(a >= v)) v = a;  // NaN propagates as "smallest"
+    }
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) {
+            const double o = s[threadIdx.x + k];
+            if (!(o >= s[threadIdx.x])) s[threadIdx.x] = o;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[1] = s[0];
+}
+
+template <typename T>
+int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out) {
+    LSX_HIP(hipMemsetAsync(d_out, 0, sizeof(double), h->stream));
+    if (m <= 0 || n <= 0) return LSX_OK;
+    hipLaunchKernelGGL(amax_kernel<T>, dim3(512), dim3(256), 0, h->stream, m, n, A, lda, d_out);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+template <typename T>
+int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out) {
+    hipLaunchKernelGGL(diag_minabs_kernel<T>, dim3(1), dim3(256), 0, h->stream, n, LU, lda, d_out);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// ------------------------------------------------------------------ copies
+template <typename T>
+__global__ void copy2d_kernel(int m, int n, const T *__restrict__ S, int lds, T *__restrict__ D,
+                              int ldd) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < n && i < m) D[(size_t)i * ldd + j] = S[(size_t)i * lds + j];
+}
+
+template <typename T>
+int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd) {
+    if (m <= 0 || n <= 0) return LSX_OK;
+    hipLaunchKernelGGL(copy2d_kernel<T>, dim3((n + 255) / 256, m), dim3(256), 0, h->stream, m, n, S,
+                       lds, D, ldd);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+#define INST(T)                                                                                   \
+    template int launch_fill<T>(lsx_handle_t, int, uint64_t, int, int, T *, int, int, int);       \
+    template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
+    template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
+    template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
+                                      int);                                                       \
+    template int launch_apply_ipiv_rows<T>(lsx_handle_t, int, int, const int32_t *, T *, int);    \
+    template int launch_set_identity_perm<T>(lsx_handle_t, int, const int32_t *, T *, int);       \
+    template int launch_det<T>(lsx_handle_t, int, const T *, int, const int32_t *, double *);     \
+    template int launch_copy2d<T>(lsx_handle_t, int, int, const T *, int, T *, int);              \
+    template int launch_gather_rows<T>(lsx_handle_t, int, int, const int32_t *, const T *, int, T *, int); \
+    template int launch_amax<T>(lsx_handle_t, int, int, const T *, int, double *);                \
+    template int launch_diag_minabs<T>(lsx_handle_t, int, const T *, int, double *);
+INST(double)
+INST(float)
+
+}  // namespace lsx

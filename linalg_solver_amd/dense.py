@@ -1,0 +1,155 @@
+"""numpy-level entry points over the C ABI (contiguous fp64 / fp32 buffers).
+
+This is the marshalling-free boundary: `Matrix` (matrix.py) converts its
+list-of-lists into one contiguous array and calls these.  Every function runs
+on the GPU through liblsx.so; none has a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+
+EPS64 = float(np.finfo(np.float64).eps)
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a: np.ndarray, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _h(handle: Optional[N.Handle]) -> N.Handle:
+    return handle if handle is not None else N.default_handle()
+
+
+def lu_factor(a, handle: Optional[N.Handle] = None, dtype=np.float64) -> Tuple[np.ndarray, np.ndarray, int]:
+    """P A = L U (partial pivoting).  Returns (LU, ipiv, info); ipiv is 0-based LAPACK style."""
+    h = _h(handle)
+    LU = np.array(a, dtype=dtype, order="C", copy=True)
+    n = LU.shape[0]
+    if LU.ndim != 2 or LU.shape[1] != n:
+        raise ValueError("lu_factor needs a square matrix")
+    ipiv = np.zeros(max(n, 1), dtype=np.int32)
+    info = C.c_int(0)
+    if dtype == np.float64:
+        N.check(h.lib.lsx_getrf_f64(h.ptr, n, _ptr(LU, C.c_double), n, _ptr(ipiv, C.c_int32), C.byref(info)), "lsx_getrf_f64")
+    elif dtype == np.float32:
+        N.check(h.lib.lsx_getrf_f32(h.ptr, n, _ptr(LU, C.c_float), n, _ptr(ipiv, C.c_int32), C.byref(info)), "lsx_getrf_f32")
+    else:
+        raise TypeError("dtype must be float64 or float32")
+    return LU, ipiv[:n], info.value
+
+
+def lu_solve(LU: np.ndarray, ipiv: np.ndarray, b, handle: Optional[N.Handle] = None) -> np.ndarray:
+    h = _h(handle)
+    dt = LU.dtype
+    LU = np.ascontiguousarray(LU)
+    n = LU.shape[0]
+    X = np.array(b, dtype=dt, order="C", copy=True)
+    vec = X.ndim == 1
+    if vec:
+        X = X.reshape(n, 1).copy()
+    if X.shape[0] != n:
+        raise ValueError("right-hand side has the wrong number of rows")
+    ipiv = np.ascontiguousarray(ipiv, dtype=np.int32)
+    if dt == np.float64:
+        N.check(h.lib.lsx_getrs_f64(h.ptr, n, X.shape[1], _ptr(LU, C.c_double), n, _ptr(ipiv, C.c_int32),
+                                    _ptr(X, C.c_double), X.shape[1]), "lsx_getrs_f64")
+    else:
+        N.check(h.lib.lsx_getrs_f32(h.ptr, n, X.shape[1], _ptr(LU, C.c_float), n, _ptr(ipiv, C.c_int32),
+                                    _ptr(X, C.c_float), X.shape[1]), "lsx_getrs_f32")
+    return X[:, 0].copy() if vec else X
+
+
+def solve(a, b, handle: Optional[N.Handle] = None, dtype=np.float64):
+    """Solve A X = B.  Returns (X, info, pivot_ratio); X is None when info != 0."""
+    h = _h(handle)
+    A = np.ascontiguousarray(a, dtype=dtype)
+    n = A.shape[0]
+    if A.ndim != 2 or A.shape[1] != n:
+        raise ValueError("solve needs a square matrix")
+    X = np.array(b, dtype=dtype, order="C", copy=True)
+    vec = X.ndim == 1
+    if vec:
+        X = X.reshape(n, 1).copy()
+    if X.shape[0] != n:
+        raise ValueError("right-hand side has the wrong number of rows")
+    info, ratio = C.c_int(0), C.c_double(1.0)
+    if dtype == np.float64:
+        N.check(h.lib.lsx_gesv_f64(h.ptr, n, X.shape[1], _ptr(A, C.c_double), n, _ptr(X, C.c_double), X.shape[1],
+                                   C.byref(info), C.byref(ratio)), "lsx_gesv_f64")
+    else:
+        N.check(h.lib.lsx_gesv_f32(h.ptr, n, X.shape[1], _ptr(A, C.c_float), n, _ptr(X, C.c_float), X.shape[1],
+                                   C.byref(info), C.byref(ratio)), "lsx_gesv_f32")
+    if info.value != 0:
+        return None, info.value, ratio.value
+    return (X[:, 0].copy() if vec else X), 0, ratio.value
+
+
+def inv(a, handle: Optional[N.Handle] = None):
+    """Returns (inverse or None, info, pivot_ratio)."""
+    h = _h(handle)
+    A = _f64(a)
+    n = A.shape[0]
+    if A.ndim != 2 or A.shape[1] != n:
+        raise ValueError("inv needs a square matrix")
+    out = np.empty_like(A)
+    info, ratio = C.c_int(0), C.c_double(1.0)
+    N.check(h.lib.lsx_getri_f64(h.ptr, n, _ptr(A, C.c_double), n, _ptr(out, C.c_double), n, C.byref(info),
+                                C.byref(ratio)), "lsx_getri_f64")
+    if info.value != 0:
+        return None, info.value, ratio.value
+    return out, 0, ratio.value
+
+
+def det_parts(a, handle: Optional[N.Handle] = None) -> Tuple[float, float, int]:
+    """det(A) = sign * mant * 2**exp2 with mant in [0.5, 1) (sign 0 for a singular matrix)."""
+    h = _h(handle)
+    A = _f64(a)
+    n = A.shape[0]
+    if A.ndim != 2 or A.shape[1] != n:
+        raise ValueError("det needs a square matrix")
+    s, m, e = C.c_double(0), C.c_double(0), C.c_int64(0)
+    N.check(h.lib.lsx_det_f64(h.ptr, n, _ptr(A, C.c_double), n, C.byref(s), C.byref(m), C.byref(e)), "lsx_det_f64")
+    return s.value, m.value, int(e.value)
+
+
+def slogdet(a, handle: Optional[N.Handle] = None) -> Tuple[float, float]:
+    s, m, e = det_parts(a, handle)
+    if s == 0.0:
+        return 0.0, -math.inf
+    return s, math.log(m) + e * math.log(2.0)
+
+
+def det(a, handle: Optional[N.Handle] = None) -> float:
+    s, m, e = det_parts(a, handle)
+    if s == 0.0:
+        return 0.0
+    try:
+        return s * math.ldexp(m, e)
+    except OverflowError:
+        return s * math.inf
+
+
+def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N.Handle] = None):
+    """Reduced row echelon form over columns [0, bar_col).  Returns (R, pivots, rank)."""
+    h = _h(handle)
+    A = _f64(a)
+    if A.ndim != 2 or A.shape[0] < 1 or A.shape[1] < 1:
+        raise ValueError("rref needs a non-empty 2-D matrix")
+    m, n = A.shape
+    R = np.empty_like(A)
+    piv = np.zeros(2 * min(m, n), dtype=np.int32)
+    rank = C.c_int(0)
+    N.check(h.lib.lsx_rref_f64(h.ptr, m, n, int(bar_col or 0), _ptr(A, C.c_double), n, _ptr(R, C.c_double), n,
+                               _ptr(piv, C.c_int32), C.byref(rank), float(tol)), "lsx_rref_f64")
+    r = rank.value
+    return R, [(int(piv[2 * i]), int(piv[2 * i + 1])) for i in range(r)], r

@@ -1,0 +1,278 @@
+"""`Matrix`: host-side mirror of the reference's row-reduction surface.
+
+Same names, argument order, defaults, return types and error behaviour as
+koskja/linalg-solver's ``linalg_solver.linalg.Matrix`` for the path this
+package replaces (citations are to /root/reference/linalg_solver/linalg.py):
+
+    Matrix(items)                      :14-32   validation, public ``items``
+    row_reduce(bar_col=None)           :534-630 -> (items, pivots, mats, steps)
+    find_preimage_of(vec, log_*...)    :632-680 -> AffineSubspace | NoSolution
+    inverse(log_*...)                  :682-743 -> Matrix | NoSolution
+    determinant(...)                   :183-207 -> scalar
+    rank()                             :745-747 -> int
+    kernel()                           :749-756
+    AffineSubspace / NoSolution        :491-532
+    zero / identity / new_vector / transpose   :410-415, 483-489
+
+All arithmetic runs on the GPU through liblsx.so (dense.py -> _native.py).
+There is no CPU fallback: entries must be Python/numpy ints or floats, anything
+else (Fraction, sympy objects, Polynomial) raises TypeError -- exact and
+symbolic entries remain the reference's job.
+
+Deliberate differences (documented in DESIGN.md):
+  * no per-step LaTeX: ``row_reduce`` returns empty ``intermediate_matrices`` /
+    ``intermediate_steps`` (these cost the reference >99 % of its run time);
+    the ``log_*`` flags are accepted and ignored.
+  * pivoting is by largest magnitude with a tolerance (eps*max(m,n)*max|A|), so
+    ``rank`` / pivot positions are those of exact arithmetic rather than the
+    rounding artefacts an exact ``== 0`` test produces on floats
+    (SURVEY.md appendix A.9).
+  * reduced entries are always ``float`` (the reference leaves untouched entries
+    as ``int``); ``determinant`` of an integer matrix is a ``float``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, List, Optional, Tuple
+
+import numpy as np
+
+from . import dense
+
+_NUMERIC = (int, float, np.integer, np.floating)
+
+
+def _as_array(items: List[List[Any]]) -> np.ndarray:
+    for row in items:
+        for v in row:
+            if not isinstance(v, _NUMERIC):
+                raise TypeError(
+                    f"linalg_solver_amd.Matrix computes on the GPU in fp64 and accepts only int/float "
+                    f"entries; got {type(v).__name__}. Exact or symbolic entries are not supported.")
+    return np.array(items, dtype=np.float64, order="C").reshape(len(items), len(items[0]) if items else 0)
+
+
+class Matrix:
+    items: List[List[Any]]
+
+    def __init__(self, items: List[List[Any]]):
+        # linalg.py:14-32 -- same checks, same messages
+        if not items:
+            raise ValueError("Matrix cannot be empty")
+        if not all(isinstance(row, list) for row in items):
+            raise ValueError("Matrix items must be a list of lists")
+        if not items[0]:
+            if any(row for row in items):
+                raise ValueError("Matrix rows cannot be empty if columns exist")
+            row_len = 0
+        else:
+            row_len = len(items[0])
+            if not all(len(row) == row_len for row in items):
+                raise ValueError("All matrix rows must have the same length")
+        self._cols = row_len
+        self.items = items
+
+    # ---- container surface ------------------------------------------------
+    def __str__(self) -> str:
+        return "\n".join(" ".join(str(v) for v in row) for row in self.items)
+
+    def __repr__(self) -> str:
+        return f"Matrix({self.items!r})"
+
+    @property
+    def rows(self) -> int:
+        return len(self.items)
+
+    @property
+    def cols(self) -> int:
+        return len(self.items[0]) if self.rows else self._cols
+
+    def get_row(self, i: int) -> List[Any]:
+        return self.items[i]
+
+    def get_col(self, j: int) -> List[Any]:
+        return [row[j] for row in self.items]
+
+    def set_item(self, i: int, j: int, value: Any):
+        self.items[i][j] = value
+        return self
+
+    @classmethod
+    def zero(cls, rows: int, cols: int) -> "Matrix":
+        return cls([[0] * cols for _ in range(rows)])
+
+    @classmethod
+    def identity(cls, size: int) -> "Matrix":
+        return cls([[1 if i == j else 0 for j in range(size)] for i in range(size)])
+
+    @classmethod
+    def new_vector(cls, items: List[Any]) -> "Matrix":
+        return cls([[v] for v in items])
+
+    @classmethod
+    def from_numpy(cls, a) -> "Matrix":
+        a = np.asarray(a)
+        if a.ndim != 2:
+            raise ValueError("from_numpy needs a 2-D array")
+        return cls(a.tolist())
+
+    def to_numpy(self) -> np.ndarray:
+        return _as_array(self.items)
+
+    def transpose(self) -> "Matrix":
+        return Matrix([[self.items[j][i] for j in range(self.rows)] for i in range(self.cols)])
+
+    def cformat(self, _arg_of: str = "") -> str:
+        body = r"\\".join(" & ".join(_fmt(v) for v in row) for row in self.items)
+        return r"\begin{pmatrix}" + body + r"\end{pmatrix}"
+
+    # ---- result carriers (linalg.py:491-532) --------------------------------
+    class AffineSubspace:
+        def __init__(self, vec: List[Any], mat: Optional["Matrix"]):
+            self.vec = vec
+            self.generators = mat
+
+        def get_one(self) -> List[Any]:
+            return self.vec
+
+        def dim(self) -> int:
+            return self.generators.cols  # raises on None exactly like the reference (:500)
+
+        def basis(self) -> List[List[Any]]:
+            return self.generators.transpose().items
+
+        def cformat(self, arg_of: str = "") -> str:
+            g = self.generators
+            point = Matrix.new_vector(self.vec).cformat()
+            if g is None or g.rows == 0 or g.cols == 0:
+                return " %s " % point
+            gens = ", ".join(Matrix.new_vector(g.get_col(i)).cformat() for i in range(g.cols))
+            span = r" \LO \left\{ %s \right\} " % gens
+            return " %s %s  " % ("" if all(v == 0 for v in self.vec) else point + " + ", span)
+
+        def __repr__(self) -> str:
+            return f"AffineSubspace(vec={self.vec!r}, generators={self.generators!r})"
+
+    class NoSolution:
+        def __repr__(self) -> str:
+            return "NoSolution()"
+
+        def cformat(self, arg_of: str = "") -> str:
+            return r"\text{Žádné řešení}"
+
+    # ---- the replaced path --------------------------------------------------
+    def _reduce(self, A: np.ndarray, bar: int) -> Tuple[np.ndarray, List[Tuple[int, int]]]:
+        """RREF of A over columns [0, bar) on the GPU -> (reduced, pivots)."""
+        m, n = A.shape
+        if bar <= 0:
+            return A.copy(), []
+        if m == bar:
+            # [A | B] with square A: blocked LU + two block solves instead of a 2n-wide
+            # Gauss-Jordan (what linalg.py:649-656 / 704-711 spell as row_reduce(bar_col=n))
+            X, info, ratio = dense.solve(A[:, :m], A[:, m:])
+            if info == 0 and ratio > dense.EPS64 * m:
+                R = np.zeros_like(A)
+                R[:, :m] = np.eye(m)
+                R[:, m:] = X
+                return R, [(k, k) for k in range(m)]
+        R, pivots, _ = dense.rref(A, bar_col=bar)
+        return R, pivots
+
+    def row_reduce(self, bar_col: int = None):
+        """linalg.py:534-630.  Returns (reduced_items, pivots, [], [])."""
+        A = _as_array(self.items)
+        n = A.shape[1]
+        if n == 0:
+            raise IndexError("list index out of range")  # reference fails at len(A[0]) / A[0][0]
+        bar = bar_col or n - 1  # :543 -- 0 and None both mean n-1
+        R, pivots = self._reduce(A, min(bar, n))
+        if bar > n and len(pivots) < A.shape[0]:
+            # the reference walks pivot_j past the last column here (:548) and fails the same way
+            raise IndexError("list index out of range")
+        return R.tolist(), pivots, [], []
+
+    def find_preimage_of(self, vec: List[Any], log_matrices: bool = False, log_steps: bool = False,
+                         log_result: bool = False) -> "Matrix.AffineSubspace | Matrix.NoSolution":
+        """All solutions of self * x = vec (linalg.py:632-680)."""
+        if self.rows != len(vec):
+            raise ValueError("Matrix dimensions must match")  # :642-643
+        logged = log_matrices or log_steps or log_result
+        A = _as_array(self.items)
+        b = _as_array([[v] for v in vec])
+        n = A.shape[1]
+        if n == 0:
+            raise IndexError("list index out of range")
+        aug = np.hstack([A, b])
+        R, pivots = self._reduce(aug, n)
+        # :913-934 with a tolerance on the right-hand side: rows below the rank have exact
+        # zero coefficients; their rhs is rounding noise unless the system is inconsistent
+        amax = float(np.max(np.abs(aug))) if aug.size else 0.0
+        rank = len(pivots)
+        xmax = float(np.max(np.abs(R[:rank, n]))) if rank else 0.0
+        rhs_tol = 8.0 * dense.EPS64 * max(A.shape) * amax * (1.0 + xmax)
+        if rank < A.shape[0] and np.any(np.abs(R[rank:, n]) > rhs_tol):
+            return Matrix.NoSolution()
+        # :937-999
+        col_of_row = {r: c for r, c in pivots}
+        pivot_cols = {c for _, c in pivots}
+        free = [j for j in range(n) if j not in pivot_cols]
+        particular: List[Any] = [0] * n
+        for r, c in col_of_row.items():
+            particular[c] = float(R[r, n])
+        gens = []
+        for fj in free:
+            g: List[Any] = [0] * n
+            g[fj] = 1
+            for r, c in col_of_row.items():
+                g[c] = -float(R[r, fj])
+            gens.append(g)
+        if gens:
+            gen_mat = Matrix([list(col) for col in zip(*gens)])  # generators are columns (:985)
+        else:
+            gen_mat = None if logged else Matrix.zero(n, 0)  # :998 vs :888
+        return Matrix.AffineSubspace(particular, gen_mat)
+
+    def inverse(self, log_matrices: bool = False, log_steps: bool = False, log_result: bool = False):
+        """linalg.py:682-743: Matrix, or NoSolution() when singular."""
+        if self.rows != self.cols:
+            raise ValueError("Matrix must be square to invert.")  # :692-693
+        A = _as_array(self.items)
+        n = A.shape[0]
+        X, info, ratio = dense.inv(A)
+        if info != 0 or not (ratio > dense.EPS64 * n):
+            return Matrix.NoSolution()  # :701 / :737
+        return Matrix(X.tolist())
+
+    def determinant(self, log_permutation_details: bool = False, use_optimal: bool = True) -> Any:
+        """linalg.py:183-207.  sign * prod(diag U) from the pivoted LU."""
+        if self.rows != self.cols:
+            raise ValueError("Determinant requires a square matrix")
+        if self.rows == 1:
+            return self.items[0][0]  # :200-201
+        return dense.det(_as_array(self.items))
+
+    def slogdet(self) -> Tuple[float, float]:
+        """(sign, log|det|): the overflow-free form of determinant() (new API)."""
+        if self.rows != self.cols:
+            raise ValueError("Determinant requires a square matrix")
+        return dense.slogdet(_as_array(self.items))
+
+    def rank(self) -> int:
+        """linalg.py:745-747."""
+        A = _as_array(self.items)
+        if A.shape[1] == 0:
+            return 0
+        return dense.rref(A, bar_col=A.shape[1])[2]
+
+    def kernel(self) -> "Matrix.AffineSubspace":
+        """linalg.py:749-756."""
+        return self.find_preimage_of([0] * self.rows)
+
+
+def _fmt(v) -> str:
+    if isinstance(v, (int, np.integer)):
+        return str(int(v))
+    f = float(v)
+    if f == math.floor(f) and abs(f) < 1e15:
+        return str(int(f))
+    return repr(f)
