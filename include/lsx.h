@@ -49,6 +49,9 @@ enum {
     LSX_ERR_INTERNAL = -5 /* in-kernel protocol timeout or invariant violated */
 };
 
+/* pivot rules of lsx_rref_* */
+enum { LSX_PIVOT_FIRST = 0, LSX_PIVOT_MAX = 1 };
+
 /* input generators: counter-based, identical on host and device */
 enum { LSX_FILL_INT5 = 0, LSX_FILL_U11 = 1 };
 
@@ -66,9 +69,11 @@ enum {
 int lsx_device_count(void);
 int lsx_create(lsx_handle_t *out, int device);
 int lsx_destroy(lsx_handle_t h);
-/* Use an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream);
- * NULL restores the handle's own stream. */
+/* Enqueue on an existing hipStream_t (e.g. torch.cuda.current_stream().cuda_stream).
+ * NULL is a valid value: HIP's default (null) stream, which is torch's default too. */
 int lsx_set_stream(lsx_handle_t h, void *hip_stream);
+/* Go back to the private non-blocking stream created by lsx_create. */
+int lsx_use_own_stream(lsx_handle_t h);
 int lsx_synchronize(lsx_handle_t h);
 /* Thread-local text of the last failure on this thread ("" if none). */
 const char *lsx_last_error(void);
@@ -100,10 +105,13 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
 /* General m x n reduced row echelon form over columns [0,bar_col) with the
  * remaining columns carried along (row_reduce, linalg.py:534-630).  bar_col <= 0
  * means n-1 (linalg.py:543).  pivots holds *rank pairs (row, col), 0-based.
- * Pivot tolerance: |pivot| <= tol counts as zero; tol < 0 selects
- * eps * max(m,n) * max|A|. */
+ * Pivot tolerance: |a| <= tol counts as zero; tol < 0 selects eps*max(m,n)*max|A|.
+ * pivot_rule LSX_PIVOT_FIRST takes the first row at or below the pivot row whose
+ * entry is non-zero -- the reference's rule (linalg.py:548-552), which also fixes
+ * the carried-along columns of rank-deficient / tall inputs; LSX_PIVOT_MAX takes
+ * the largest magnitude (same pivot positions, better conditioning). */
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda,
-                 double *R, int ldr, int32_t *pivots, int *rank, double tol);
+                 double *R, int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule);
 
 /* ---- host-buffer entry points (fp32; BASELINE config 5) ------------------- */
 int lsx_getrf_f32(lsx_handle_t h, int n, float *A, int lda, int32_t *ipiv, int *info);
@@ -126,7 +134,7 @@ int lsx_getrf_f32_dev(lsx_handle_t h, int n, float *dA, int lda, int32_t *d_ipiv
 int lsx_getrs_f32_dev(lsx_handle_t h, int n, int nrhs, const float *dLU, int lda,
                       const int32_t *d_ipiv, float *dB, int ldb);
 int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
-                     int32_t *d_pivots, int *d_rank, double tol);
+                     int32_t *d_pivots, int *d_rank, double tol, int pivot_rule);
 
 /* Building blocks used by the multi-GPU driver (1-D block-cyclic columns,
  * SURVEY.md section 8e); all on device pointers, row-major. */
@@ -160,6 +168,10 @@ int lsx_prof_enable(lsx_handle_t h, int on);
 int lsx_prof_reset(lsx_handle_t h);
 int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, double *flops,
                   double *bytes);
+
+/* Diagnostics: sustained MFMA rate of a register-resident loop (synchronous).
+ * is_f32 = 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f32_16x16x4_f32. */
+int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "liblsx.so")
 
 PROF_BUCKETS = {"panel": 0, "laswp": 1, "trsm": 2, "gemm": 3, "other": 4}
 FILL_INT5, FILL_U11 = 0, 1
+PIVOT_FIRST, PIVOT_MAX = 0, 1
 
 
 class LsxError(RuntimeError):
@@ -33,6 +34,7 @@ _SIGS = {
     "lsx_create": [C.POINTER(_vp), _i],
     "lsx_destroy": [_vp],
     "lsx_set_stream": [_vp, _vp],
+    "lsx_use_own_stream": [_vp],
     "lsx_synchronize": [_vp],
     "lsx_set_option": [_vp, C.c_char_p, _i],
     "lsx_get_option": [_vp, C.c_char_p, C.POINTER(_i)],
@@ -41,7 +43,7 @@ _SIGS = {
     "lsx_gesv_f64": [_vp, _i, _i, _dp, _i, _dp, _i, C.POINTER(_i), _dp],
     "lsx_getri_f64": [_vp, _i, _dp, _i, _dp, _i, C.POINTER(_i), _dp],
     "lsx_det_f64": [_vp, _i, _dp, _i, _dp, _dp, C.POINTER(C.c_int64)],
-    "lsx_rref_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, _ip, C.POINTER(_i), C.c_double],
+    "lsx_rref_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, _ip, C.POINTER(_i), C.c_double, _i],
     "lsx_getrf_f32": [_vp, _i, _fp, _i, _ip, C.POINTER(_i)],
     "lsx_getrs_f32": [_vp, _i, _i, _fp, _i, _ip, _fp, _i],
     "lsx_gesv_f32": [_vp, _i, _i, _fp, _i, _fp, _i, C.POINTER(_i), _dp],
@@ -51,7 +53,7 @@ _SIGS = {
     "lsx_det_f64_dev": [_vp, _i, _vp, _i, _vp, _vp],
     "lsx_getrf_f32_dev": [_vp, _i, _vp, _i, _vp, _vp],
     "lsx_getrs_f32_dev": [_vp, _i, _i, _vp, _i, _vp, _vp, _i],
-    "lsx_rref_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, C.c_double],
+    "lsx_rref_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _vp, C.c_double, _i],
     "lsx_panel_f64_dev": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "lsx_laswp_f64_dev": [_vp, _i, _vp, _i, _i, _i, _vp],
     "lsx_trsm_lu_f64_dev": [_vp, _i, _i, _vp, _i, _vp, _i],
@@ -59,6 +61,7 @@ _SIGS = {
     "lsx_gemm_sub_f32_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
     "lsx_fill_f64_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
+    "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],
     "lsx_prof_read": [_vp, _i, _dp, C.POINTER(C.c_longlong), _dp, _dp],
@@ -66,8 +69,29 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["lsx_device_count", "lsx_last_error"])
 
 
+def _hip_runtime_path() -> str:
+    """The ONE HIP runtime this process should use.  torch wheels bundle their own
+    libamdhip64 (same SONAME as /opt/rocm's); two copies in one process break device
+    discovery for whichever initialises second, so prefer torch's when torch is installed."""
+    import importlib.util
+
+    cands = []
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            cands.append(os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so")]
+    for c in cands:
+        if os.path.exists(c):
+            return c
+    raise LsxError("no libamdhip64 found (looked in torch/lib and $ROCM_PATH/lib)")
+
+
 def load():
-    """dlopen liblsx.so (no device is touched yet)."""
+    """dlopen the HIP runtime, then liblsx.so (no device is touched yet)."""
     global _lib
     with _lock:
         if _lib is None:
@@ -75,6 +99,7 @@ def load():
                 raise LsxError(
                     f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                     "g.build()'` (hipcc --offload-arch=gfx950). This package has no CPU fallback.")
+            C.CDLL(_hip_runtime_path(), mode=C.RTLD_GLOBAL)
             L = C.CDLL(LIB_PATH)
             for name, args in _SIGS.items():
                 fn = getattr(L, name)
@@ -127,10 +152,19 @@ class Handle:
         return v.value
 
     def set_stream(self, stream_ptr: int):
-        check(self.lib.lsx_set_stream(self._h, _vp(stream_ptr)), "lsx_set_stream")
+        """Enqueue on this hipStream_t; 0 / None is HIP's default stream (torch's default too)."""
+        check(self.lib.lsx_set_stream(self._h, _vp(stream_ptr or None)), "lsx_set_stream")
+
+    def use_own_stream(self):
+        check(self.lib.lsx_use_own_stream(self._h), "lsx_use_own_stream")
 
     def synchronize(self):
         check(self.lib.lsx_synchronize(self._h), "lsx_synchronize")
+
+    def mfma_peak(self, is_f32: bool = False, iters: int = 20000, blocks_per_cu: int = 1) -> float:
+        t = C.c_double(0)
+        check(self.lib.lsx_diag_mfma_peak(self._h, 1 if is_f32 else 0, iters, blocks_per_cu, C.byref(t)))
+        return t.value
 
     # measurement
     def prof_enable(self, on: bool = True):

@@ -92,7 +92,8 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     if (n == 0) return LSX_OK;
     const int nb = h->nb;
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) + 4096));
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
+                                  ((size_t)n / 128 + 2) * 2112 + 4096));
     const size_t tinv_elems = (size_t)((nb + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
     T *Tinv = (T *)h->ws2;
@@ -333,7 +334,14 @@ int lsx_destroy(lsx_handle_t h) {
 int lsx_set_stream(lsx_handle_t h, void *hip_stream) {
     LSX_ARG(h);
     LSX_HIP(hipStreamSynchronize(h->stream));
-    h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+    h->stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
+    return LSX_OK;
+}
+
+int lsx_use_own_stream(lsx_handle_t h) {
+    LSX_ARG(h);
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    h->stream = h->own_stream;
     return LSX_OK;
 }
 
@@ -451,8 +459,9 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
 }
 
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
-                 int ldr, int32_t *pivots, int *rank, double tol) {
+                 int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
     LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && rank);
+    LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
     const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
     LSX_ARG(bar <= n);
     const int ld = ld_for(n);
@@ -464,7 +473,7 @@ int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int
     int32_t *dp = c.take<int32_t>(2 * (size_t)np);
     int *drank = c.take<int>(1);
     LSX_TRY(h2d<double>(h, m, n, A, lda, dR, ld));
-    LSX_TRY(launch_rref<double>(h, m, n, bar, dR, ld, dp, drank, tol));
+    LSX_TRY(launch_rref<double>(h, m, n, bar, dR, ld, dp, drank, tol, pivot_rule));
     LSX_TRY(d2h<double>(h, m, n, dR, ld, R, ldr));
     int hr = 0;
     LSX_HIP(hipMemcpyAsync(&hr, drank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -504,18 +513,19 @@ int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int
     return launch_det<double>(h, n, dLU, lda, d_ipiv, d_out);
 }
 int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
-                     int32_t *d_pivots, int *d_rank, double tol) {
+                     int32_t *d_pivots, int *d_rank, double tol, int pivot_rule) {
     LSX_ARG(h && m >= 1 && n >= 1 && ldr >= n && dR && d_pivots);
+    LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
     const int bar = bar_col > 0 ? bar_col : n - 1;
     LSX_ARG(bar <= n);
     LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096));
-    return launch_rref<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol);
+    return launch_rref<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol, pivot_rule);
 }
 
 int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,
                       int *d_info) {
     LSX_ARG(h && m >= jb && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + 4096));
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 128 + 2) * 2112 + 4096));
     return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
 }
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
@@ -551,6 +561,11 @@ int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, floa
                      int row_off, int col_off) {
     LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
     return launch_fill<float>(h, kind, seed, m, n, dA, lda, row_off, col_off);
+}
+
+int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops) {
+    LSX_ARG(h && tflops && iters > 0 && blocks_per_cu >= 1 && blocks_per_cu <= 8);
+    return diag_mfma_peak(h, is_f32, iters, blocks_per_cu, tflops);
 }
 
 // ---- measurement

@@ -130,12 +130,13 @@ template <typename T>
 int launch_det(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, double *d_out);
 template <typename T>
 int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots,
-                int *d_rank, double tol);
+                int *d_rank, double tol, int pivot_rule);
 // d_out[0] = max|A_ij| ; d_out[1] = min_k |LU_kk|
 template <typename T>
 int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out);
 template <typename T>
 int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out);
+int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops);
 template <typename T>
 int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd);
 

@@ -168,6 +168,10 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
     if (m <= 0 || jb <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_PANEL, 0, 2.0 * sizeof(T) * m * (double)jb);
     // the panel's first column is global column row0 (square LU: panel starts on the diagonal)
+    if (h->panel_mode == 1) {
+        const int r = panel_cooperative<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
+        if (r != 1) return r;  // 1 = shape not supported by the cooperative kernel
+    }
     return panel_percolumn<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
 }
 

@@ -5,13 +5,19 @@
 // including the zero-column skip (linalg.py:565-567: pivot row stays, column
 // advances) and the carried-along columns right of bar_col.
 //
-// Differences from the reference, by design:
-//   - pivot = largest |a| in the column at or below the pivot row (the
-//     reference takes the first non-zero); a column whose largest entry is
-//     <= tol counts as a zero column and its sub-pivot entries are set to
-//     exactly 0.  In exact arithmetic both give the same RREF and the same
-//     pivot positions; in floating point the tolerance makes rank the
-//     mathematical rank instead of a rounding artefact.
+// Pivot rule (selectable):
+//   - LSX_PIVOT_FIRST (default of the Python surface): the first row at or
+//     below the pivot row whose entry is non-zero, exactly the reference's rule
+//     (linalg.py:548-552).  This matters beyond style: with rank < m or
+//     bar_col < n the carried-along columns depend on WHICH rows become pivot
+//     rows, so only this rule reproduces the reference's numbers there.
+//   - LSX_PIVOT_MAX: largest |a| (partial pivoting); same pivot positions and
+//     same left block, better conditioned on large inputs.
+// Difference from the reference, by design:
+//   - "non-zero" means |a| > tol; a column with no such entry counts as a zero
+//     column and its sub-pivot entries are set to exactly 0.  In exact
+//     arithmetic this is the reference's test; in floating point it makes rank
+//     the mathematical rank instead of a rounding artefact.
 //   - elimination above and below the pivot happens in the same sweep
 //     (Gauss-Jordan) instead of a separate backward pass (linalg.py:611-629).
 //
@@ -31,8 +37,9 @@ struct RrefState {
     int pending;  // 1: a pivot was placed in the previous column, pi/rank not yet advanced
     int skip;     // 1: current column has no pivot
     int pad[3];
-    double tol;
-    double amax;
+    double tol;        // fixed tolerance (user) or < 0: eps_scale * amax, re-evaluated per column
+    double amax;       // running max |entry| of the working matrix (grows with elimination)
+    double eps_scale;  // eps * max(m, n)
 };
 
 template <typename T>
@@ -58,12 +65,13 @@ __global__ __launch_bounds__(256) void rref_amax_kernel(int m, int ncols, const 
 
 __global__ void rref_init_kernel(RrefState *st, double tol, double eps_scale) {
     st->pi = 0; st->rank = 0; st->p = 0; st->pending = 0; st->skip = 1;
-    st->tol = tol >= 0 ? tol : eps_scale * st->amax;
+    st->tol = tol;
+    st->eps_scale = eps_scale;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void rref_pivot_kernel(int m, int n, int pj, T *__restrict__ R,
-                                                         int ldr, RrefState *st,
+__global__ __launch_bounds__(256) void rref_pivot_kernel(int m, int n, int pj, int pivot_rule,
+                                                         T *__restrict__ R, int ldr, RrefState *st,
                                                          int32_t *__restrict__ pivots,
                                                          T *__restrict__ prow, T *__restrict__ orow) {
     __shared__ double s_v[256];
@@ -76,10 +84,14 @@ __global__ __launch_bounds__(256) void rref_pivot_kernel(int m, int n, int pj, T
         if (tid == 0) st->skip = 1;
         return;
     }
+    // rounding noise scales with the largest magnitude the elimination has produced so far
+    const double tol = st->tol >= 0 ? st->tol : st->eps_scale * st->amax;
     double v = -1;
     int vi = 0x7fffffff;
     for (int i = pi + tid; i < m; i += 256) {
-        const double a = fabs((double)R[(size_t)i * ldr + pj]);
+        double a = fabs((double)R[(size_t)i * ldr + pj]);
+        // FIRST rule: every non-zero entry scores the same, so the lowest row index wins below
+        if (pivot_rule == LSX_PIVOT_FIRST) a = (a > tol) ? 1.0e300 : 0.0;
         if (a > v) { v = a; vi = i; }
     }
     s_v[tid] = v; s_i[tid] = vi;
@@ -94,7 +106,7 @@ __global__ __launch_bounds__(256) void rref_pivot_kernel(int m, int n, int pj, T
     }
     const double best = s_v[0];
     const int p = s_i[0];
-    if (!(best > st->tol)) {  // zero column (or NaN): clear the sub-pivot entries, move on
+    if (!(best > tol)) {  // zero column (or NaN): clear the sub-pivot entries, move on
         for (int i = pi + tid; i < m; i += 256) R[(size_t)i * ldr + pj] = T(0);
         if (tid == 0) st->skip = 1;
         return;
@@ -116,7 +128,7 @@ __global__ __launch_bounds__(256) void rref_pivot_kernel(int m, int n, int pj, T
 // with a non-zero entry in column pj is eliminated in place.
 template <typename T>
 __global__ __launch_bounds__(256) void rref_sweep_kernel(int m, int n, int pj, T *__restrict__ R,
-                                                         int ldr, const RrefState *st,
+                                                         int ldr, RrefState *st,
                                                          const T *__restrict__ prow,
                                                          const T *__restrict__ orow) {
     if (st->skip) return;
@@ -132,7 +144,16 @@ __global__ __launch_bounds__(256) void rref_sweep_kernel(int m, int n, int pj, T
     const T *src = (i == p) ? orow : row;
     const T f = src[pj];
     if (f == T(0) && i != p) return;  // linalg.py:589
-    for (int c = pj + lane; c < n; c += 64) row[c] = src[c] - f * prow[c];
+    double vmax = 0;
+    for (int c = pj + lane; c < n; c += 64) {
+        const T v = src[c] - f * prow[c];
+        row[c] = v;
+        vmax = fmax(vmax, fabs((double)v));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmax(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0 && vmax > st->amax)
+        atomicMax((unsigned long long *)&st->amax, (unsigned long long)__double_as_longlong(vmax));
 }
 
 __global__ void rref_finish_kernel(RrefState *st, int *d_rank) {
@@ -142,7 +163,7 @@ __global__ void rref_finish_kernel(RrefState *st, int *d_rank) {
 
 template <typename T>
 int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots, int *d_rank,
-                double tol) {
+                double tol, int pivot_rule) {
     ProfScope ps(h, LSX_PROF_OTHER);
     // scratch: state | prow[n] | orow[n]
     const size_t need = 256 + 2 * (size_t)n * sizeof(T);
@@ -159,8 +180,8 @@ int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d
     const double eps_scale = (double)Real<T>::eps * (double)(m > n ? m : n);
     hipLaunchKernelGGL(rref_init_kernel, dim3(1), dim3(1), 0, h->stream, st, tol, eps_scale);
     for (int pj = 0; pj < bar; ++pj) {
-        hipLaunchKernelGGL(rref_pivot_kernel<T>, dim3(1), dim3(256), 0, h->stream, m, n, pj, R, ldr, st,
-                           d_pivots, prow, orow);
+        hipLaunchKernelGGL(rref_pivot_kernel<T>, dim3(1), dim3(256), 0, h->stream, m, n, pj, pivot_rule,
+                           R, ldr, st, d_pivots, prow, orow);
         hipLaunchKernelGGL(rref_sweep_kernel<T>, dim3((m + 3) / 4), dim3(256), 0, h->stream, m, n, pj,
                            R, ldr, st, prow, orow);
     }
@@ -169,7 +190,9 @@ int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d
     return LSX_OK;
 }
 
-template int launch_rref<double>(lsx_handle_t, int, int, int, double *, int, int32_t *, int *, double);
-template int launch_rref<float>(lsx_handle_t, int, int, int, float *, int, int32_t *, int *, double);
+template int launch_rref<double>(lsx_handle_t, int, int, int, double *, int, int32_t *, int *, double,
+                                 int);
+template int launch_rref<float>(lsx_handle_t, int, int, int, float *, int, int32_t *, int *, double,
+                                int);
 
 }  // namespace lsx

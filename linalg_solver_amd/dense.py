@@ -139,8 +139,10 @@ def det(a, handle: Optional[N.Handle] = None) -> float:
         return s * math.inf
 
 
-def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N.Handle] = None):
-    """Reduced row echelon form over columns [0, bar_col).  Returns (R, pivots, rank)."""
+def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N.Handle] = None,
+         pivot_rule: int = N.PIVOT_FIRST):
+    """Reduced row echelon form over columns [0, bar_col).  Returns (R, pivots, rank).
+    pivot_rule: N.PIVOT_FIRST = the reference's first-non-zero rule, N.PIVOT_MAX = largest |a|."""
     h = _h(handle)
     A = _f64(a)
     if A.ndim != 2 or A.shape[0] < 1 or A.shape[1] < 1:
@@ -150,6 +152,6 @@ def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N
     piv = np.zeros(2 * min(m, n), dtype=np.int32)
     rank = C.c_int(0)
     N.check(h.lib.lsx_rref_f64(h.ptr, m, n, int(bar_col or 0), _ptr(A, C.c_double), n, _ptr(R, C.c_double), n,
-                               _ptr(piv, C.c_int32), C.byref(rank), float(tol)), "lsx_rref_f64")
+                               _ptr(piv, C.c_int32), C.byref(rank), float(tol), int(pivot_rule)), "lsx_rref_f64")
     r = rank.value
     return R, [(int(piv[2 * i]), int(piv[2 * i + 1])) for i in range(r)], r

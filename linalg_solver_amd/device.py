@@ -114,11 +114,11 @@ class DeviceSolver:
         N.check(self.lib.lsx_trsm_lu_f64_dev(self.h.ptr, L.shape[0], B.shape[1], L.data_ptr(), L.stride(0),
                                              B.data_ptr(), B.stride(0)), "trsm_lu_dev")
 
-    def rref_(self, R: torch.Tensor, bar_col: int = 0, tol: float = -1.0):
+    def rref_(self, R: torch.Tensor, bar_col: int = 0, tol: float = -1.0, pivot_rule: int = N.PIVOT_FIRST):
         _rowmajor(R, "rref_")
         m, n = R.shape
         piv = torch.zeros(2 * min(m, n), dtype=torch.int32, device=R.device)
         rank = torch.zeros(1, dtype=torch.int32, device=R.device)
         N.check(self.lib.lsx_rref_f64_dev(self.h.ptr, m, n, bar_col, R.data_ptr(), R.stride(0), piv.data_ptr(),
-                                          rank.data_ptr(), tol), "rref_dev")
+                                          rank.data_ptr(), tol, pivot_rule), "rref_dev")
         return piv, rank

@@ -175,7 +175,14 @@ class Matrix:
                 R[:, :m] = np.eye(m)
                 R[:, m:] = X
                 return R, [(k, k) for k in range(m)]
-        R, pivots, _ = dense.rref(A, bar_col=bar)
+        # rank and pivot positions from the well-conditioned rule (largest |a|) ...
+        R, pivots, rank = dense.rref(A, bar_col=bar, pivot_rule=dense.N.PIVOT_MAX)
+        if rank < m:
+            # ... but with rank < m the carried-along columns depend on WHICH rows became pivot
+            # rows, so reproduce the reference's choice (first non-zero row, linalg.py:548-552)
+            R1, pivots1, _ = dense.rref(A, bar_col=bar, pivot_rule=dense.N.PIVOT_FIRST)
+            if pivots1 == pivots:
+                R = R1
         return R, pivots
 
     def row_reduce(self, bar_col: int = None):

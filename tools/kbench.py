@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmarks on one MI355X (development tool, not the contract bench).
+
+    python tools/kbench.py mfma | gemm | panel | lu [--n N] [--nb NB]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from linalg_solver_amd import gen  # noqa: E402
+from linalg_solver_amd.device import DeviceSolver  # noqa: E402
+
+
+def timeit(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(reps):
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return min(ts), sorted(ts)[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="+")
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--nb", type=int, default=128)
+    args = ap.parse_args()
+    dev = DeviceSolver()
+    if "mfma" in args.what:
+        for bpc in (1, 2):
+            print(f"mfma f64 peak ({bpc} WG/CU): {dev.h.mfma_peak(False, 20000, bpc):.1f} TFLOP/s   "
+                  f"f32: {dev.h.mfma_peak(True, 20000, bpc):.1f} TFLOP/s", flush=True)
+    if "gemm" in args.what:
+        for dt in (torch.float64, torch.float32):
+            for m, k in ((8064, 128), (4096, 128), (2048, 128), (1024, 128), (8064, 256), (4096, 256), (8064, 64)):
+                A = torch.randn(m, k, dtype=dt, device="cuda")
+                B = torch.randn(k, m, dtype=dt, device="cuda")
+                Cm = torch.randn(m, m, dtype=dt, device="cuda")
+                tmin, tmed = timeit(lambda: dev.gemm_sub_(Cm, A, B))
+                fl = 2.0 * m * m * k
+                by = 2.0 * Cm.element_size() * m * m
+                print(f"gemm_sub {str(dt)[6:]} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
+                      f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
+    if "panel" in args.what:
+        for mode in (1, 0):
+            dev.h.set_option("panel", mode)
+            for m in (args.n, args.n // 2, args.n // 8, 256):
+                P0 = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+                dev.fill_(P0, gen.U11, 3)
+                ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                P = P0.clone()
+
+                def run():
+                    P.copy_(P0)
+                    dev.panel_(P, 0, ipiv, info)
+                tmin, tmed = timeit(run, reps=5, warm=1)
+                tcopy, _ = timeit(lambda: P.copy_(P0), reps=5, warm=1)
+                t = tmin - tcopy
+                print(f"panel mode={mode} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)  "
+                      f"{2 * 8 * m * args.nb / t / 1e6:.1f} GB/s", flush=True)
+    if "lu" in args.what:
+        n = args.n
+        A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+        dev.fill_(A0, gen.U11, 1)
+        A = A0.clone()
+        ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for mode in (1, 0):
+            for nb in (64, 128):
+                dev.h.set_option("panel", mode)
+                dev.h.set_option("nb", nb)
+
+                def run():
+                    A.copy_(A0)
+                    dev.getrf_(A, ipiv, info)
+                tmin, _ = timeit(run, reps=3, warm=1)
+                tcopy, _ = timeit(lambda: A.copy_(A0), reps=3, warm=1)
+                t = tmin - tcopy
+                dev.h.prof_reset(); dev.h.prof_enable(True); run(); torch.cuda.synchronize()
+                dev.h.prof_enable(False)
+                pr = dev.h.prof_read()
+                print(f"getrf n={n} panel={mode} nb={nb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
+                      + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
