@@ -62,6 +62,7 @@ _SIGS = {
     "lsx_fill_f64_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp],
+    "lsx_diag_read_scratch": [_vp, C.c_size_t, _vp, C.c_size_t],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],
     "lsx_prof_read": [_vp, _i, _dp, C.POINTER(C.c_longlong), _dp, _dp],
@@ -165,6 +166,11 @@ class Handle:
         t = C.c_double(0)
         check(self.lib.lsx_diag_mfma_peak(self._h, 1 if is_f32 else 0, iters, blocks_per_cu, C.byref(t)))
         return t.value
+
+    def read_scratch(self, offset: int, nbytes: int) -> bytes:
+        buf = C.create_string_buffer(nbytes)
+        check(self.lib.lsx_diag_read_scratch(self._h, offset, buf, nbytes), "diag_read_scratch")
+        return buf.raw
 
     # measurement
     def prof_enable(self, on: bool = True):

@@ -44,7 +44,7 @@ static int ensure_scratch(lsx_handle_t h, size_t bytes) {
     return grow(&h->scratch, &h->scratch_bytes, bytes);
 }
 
-ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : h(h_) {
+ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : h(h_), st(h_->stream) {
     Prof &p = h->prof;
     if (!p.on) return;
     ProfEvent ev;
@@ -57,7 +57,7 @@ ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : 
             return;
         }
     }
-    (void)hipEventRecord(ev.a, h->stream);
+    (void)hipEventRecord(ev.a, st);
     p.pending.push_back(ev);
     idx = (int)p.pending.size() - 1;
     p.launches[bucket] += 1;
@@ -66,7 +66,7 @@ ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : 
 }
 
 ProfScope::~ProfScope() {
-    if (idx >= 0) (void)hipEventRecord(h->prof.pending[idx].b, h->stream);
+    if (idx >= 0) (void)hipEventRecord(h->prof.pending[idx].b, st);
 }
 
 // simple bump carving of a device block
@@ -85,6 +85,61 @@ struct Carver {
 
 static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---------------------------------------------------------------- look-ahead LU driver
+// Right-looking LU with look-ahead depth 1.  The update of step k is split: the columns of
+// the NEXT panel are updated first, then that panel is factored on the high-priority side
+// stream while the main stream updates the rest of the trailing matrix.  The panel chain
+// (latency-bound: one cross-CU exchange per column) thus runs underneath the MFMA work.
+//   main:  wait P(k) | laswp | trsm | gemm(next panel cols) | record N(k) | gemm(rest) ...
+//   side:                                   wait N(k) | panel(k+1) | record P(k+1)
+// Disjointness: panel(k+1) owns columns [k+jb, k+2jb) x rows >= k+jb; gemm(rest) writes
+// columns >= k+2jb and reads L21 (columns [k,k+jb)) and U12 (rows [k,k+jb)).
+template <typename T>
+static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv) {
+    const int nb = h->nb;
+    hipStream_t main_s = h->stream, side = h->side_stream;
+    struct OnSide {  // launches inside this scope go to the side stream
+        lsx_handle_t h; hipStream_t keep;
+        OnSide(lsx_handle_t h_, hipStream_t s) : h(h_), keep(h_->stream) { h->stream = s; }
+        ~OnSide() { h->stream = keep; }
+    };
+    // the side stream starts after everything already queued on the main stream (info memset, fills)
+    LSX_HIP(hipEventRecord(h->ev_start, main_s));
+    LSX_HIP(hipStreamWaitEvent(side, h->ev_start, 0));
+    {
+        OnSide g(h, side);
+        const int jb0 = n < nb ? n : nb;
+        LSX_TRY(launch_panel<T>(h, n, jb0, A, lda, 0, d_ipiv, d_info));
+        LSX_HIP(hipEventRecord(h->ev_panel, side));
+    }
+    for (int k = 0; k < n; k += nb) {
+        const int jb = (n - k < nb) ? n - k : nb;
+        T *Akk = A + (size_t)k * lda + k;
+        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));  // panel k is factored
+        LSX_TRY(launch_laswp<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        const int rest = n - k - jb;
+        if (rest <= 0) break;
+        T *A12 = A + (size_t)k * lda + k + jb;
+        T *L21 = A + (size_t)(k + jb) * lda + k;
+        T *A22 = A + (size_t)(k + jb) * lda + k + jb;
+        LSX_TRY(launch_laswp<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
+        LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
+        LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Tinv, A12, lda));
+        const int jb2 = rest < nb ? rest : nb;  // width of the next panel
+        LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
+        LSX_HIP(hipEventRecord(h->ev_next, main_s));
+        LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+        {
+            OnSide g(h, side);
+            LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
+            LSX_HIP(hipEventRecord(h->ev_panel, side));
+        }
+        if (rest > jb2)
+            LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
+    }
+    return LSX_OK;
+}
+
 // ---------------------------------------------------------------- blocked LU driver
 template <typename T>
 static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info) {
@@ -93,11 +148,12 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     const int nb = h->nb;
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
-                                  ((size_t)n / 128 + 2) * 2112 + 4096));
+                                  ((size_t)n / 64 + 2) * 5248 + 8192));
     const size_t tinv_elems = (size_t)((nb + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
     T *Tinv = (T *)h->ws2;
     if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
+    if (h->lookahead && n > 2 * nb) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv);
     for (int k = 0; k < n; k += nb) {
         const int jb = (n - k < nb) ? n - k : nb;
         T *Akk = A + (size_t)k * lda + k;
@@ -310,6 +366,19 @@ int lsx_create(lsx_handle_t *out, int device) {
         return LSX_ERR_HIP;
     }
     h->stream = h->own_stream;
+    {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = most urgent
+        if (hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_next, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
+            set_error("could not create the look-ahead stream / events");
+            (void)hipStreamDestroy(h->own_stream);
+            delete h;
+            return LSX_ERR_HIP;
+        }
+    }
     int r = grow(&h->scratch, &h->scratch_bytes, 1 << 20);
     if (r != LSX_OK) { (void)hipStreamDestroy(h->own_stream); delete h; return r; }
     *out = h;
@@ -326,6 +395,10 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
+    if (h->ev_next) (void)hipEventDestroy(h->ev_next);
+    if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return LSX_OK;
@@ -359,6 +432,11 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_mode = value;
+    } else if (!strcmp(key, "panel_rt")) {
+        LSX_ARG(value == 4 || value == 8);
+        h->panel_rt = value;
+    } else if (!strcmp(key, "panel_debug")) {
+        h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
         LSX_ARG(value == 0 || value == 1);
         h->lookahead = value;
@@ -374,6 +452,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     if (!strcmp(key, "nb")) *value = h->nb;
     else if (!strcmp(key, "panel")) *value = h->panel_mode;
     else if (!strcmp(key, "lookahead")) *value = h->lookahead;
+    else if (!strcmp(key, "panel_rt")) *value = h->panel_rt;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
     return LSX_OK;
@@ -524,8 +603,8 @@ int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int 
 
 int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,
                       int *d_info) {
-    LSX_ARG(h && m >= jb && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 128 + 2) * 2112 + 4096));
+    LSX_ARG(h && m >= 1 && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 64 + 2) * 5248 + 8192));
     return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
 }
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
@@ -561,6 +640,13 @@ int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, floa
                      int row_off, int col_off) {
     LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
     return launch_fill<float>(h, kind, seed, m, n, dA, lda, row_off, col_off);
+}
+
+int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes) {
+    LSX_ARG(h && dst && offset + bytes <= h->scratch_bytes);
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    LSX_HIP(hipMemcpy(dst, (char *)h->scratch + offset, bytes, hipMemcpyDeviceToHost));
+    return LSX_OK;
 }
 
 int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops) {

@@ -57,10 +57,14 @@ struct lsx_handle_s {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // stream in use (own or borrowed)
+    hipStream_t side_stream = nullptr;  // high-priority stream for the look-ahead panel
+    hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_start = nullptr;
     // tunables
     int nb = 128;        // panel width
-    int panel_mode = 0;  // 0 = per-column launches, 1 = cooperative kernel
-    int lookahead = 0;
+    int panel_mode = 1;  // 0 = per-column launches, 1 = cooperative kernel
+    int lookahead = 0;   // 1: factor panel k+1 on side_stream under the trailing update of step k
+    int panel_rt = 4;     // rows per thread in the cooperative panel (4 or 8)
+    int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     int num_cu = 256;
     // persistent device workspace (grown on demand, never shrunk)
     void *ws = nullptr;      // staging of caller matrices (host-buffer entry points)
@@ -82,6 +86,7 @@ int ensure_ws(lsx_handle_t h, size_t bytes);
 // RAII-less profiling bracket: call begin() before a launch group, end() after.
 struct ProfScope {
     lsx_handle_t h;
+    hipStream_t st;
     int idx = -1;
     ProfScope(lsx_handle_t h_, int bucket, double flops = 0, double bytes = 0);
     ~ProfScope();

@@ -11,23 +11,32 @@
 // {8*tx + c}, an RT x 8 tile.  HBM traffic is the algorithmic minimum: every
 // panel element is read once and written once.
 //
-// Per column j (the only cross-CU traffic is one small exchange):
-//   A. threads owning column j put it in LDS and reduce to the workgroup's
-//      candidate (largest |a| among rows not yet used as pivots).
-//   B. the wave that holds the candidate row publishes it: 128-entry row +
-//      16-byte header {|a|, row, epoch} with write-through (sc1) stores, header
-//      after an `s_waitcnt vmcnt(0)` (guide G16 recipe R1, one storing wave).
-//   C. wave 0 of every workgroup polls all G headers (one per lane, relaxed sc1
-//      loads), all reduce to the same winner (largest |a|, lowest row on ties),
-//      fetch the winner's row with sc1 loads, and put it in LDS.
-//   D. every thread updates its tile: l = a[:,j]/pivot kept in place (unit-lower
-//      L), a[:,c] -= l * u[c] for c > j (linalg.py:587-596).
+// Per column j the only cross-CU traffic is one exchange, and the bulk of the
+// arithmetic is scheduled UNDER its latency:
+//   1. apply the previous column's update to column j only; threads owning
+//      column j put it in LDS and reduce to the workgroup's candidate (largest
+//      |a| among rows not yet used as pivots).
+//   2. the wave holding the candidate row brings that one row up to date and
+//      publishes it as 128 self-validating 16-byte granules {value, epoch} plus a
+//      16-byte header {|a|, row, epoch, checksum} -- write-through (sc1) stores,
+//      NO drain and no flag: every granule carries its own tag (guide G16 R2).
+//   3. all threads now apply the deferred rank-1 update of column j-1 to the rest
+//      of their tile (linalg.py:587-596) while the exchange is in flight; one idle
+//      lane replays the previous interchange on the position maps.
+//   4. wave 0 polls the G headers (one per lane, relaxed sc1 loads), every
+//      workgroup reduces to the same winner (largest |a|, lowest row on ties),
+//      then reads the winner's granules until all 128 tags match, and puts the
+//      row in LDS.
+//   5. every thread derives its multipliers l = a[:,j]/pivot (kept in place:
+//      unit-lower L) and keeps (l, u) in registers as the next deferred update.
 // Rows never move during the loop ("implicit pivoting": used rows are frozen).
 // The LAPACK interchange list ipiv and each row's final position are obtained by
-// replaying the swaps on two jb-entry maps as the pivots are chosen; at the end
-// every row is written straight to its final position.
+// replaying the swaps on two jb-entry maps; at the end every row is written
+// straight to its final position.
 //
 // Every spin is bounded; a timeout sets *status and lets the grid drain.
+#include <type_traits>
+
 #include "common.h"
 
 namespace lsx {
@@ -35,6 +44,7 @@ namespace lsx {
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 
 constexpr int PC_COLS = 128;   // column capacity (16 thread columns x 8)
+constexpr int HDR_STRIDE = 512;  // bytes between headers: one line / channel each, not 16 B apart
 constexpr int SPIN_LIMIT = 1 << 20;   // ~1 s of polling before a workgroup gives up
 
 struct __attribute__((aligned(16))) XHdr {
@@ -49,18 +59,34 @@ __device__ __forceinline__ unsigned fold16(double v) {
     return (x ^ (x >> 16)) & 0xffffu;
 }
 
-template <typename T, int RT>
+struct __attribute__((aligned(16))) XGran {
+    unsigned long long bits;  // value (fp64 bits, or fp32 bits in the low half)
+    unsigned epoch;
+    unsigned pad;
+};
+
+// DBG = true builds the stamped diagnostic variant: wave 0 accumulates, per segment of
+// the column loop, 100 MHz wall-clock ticks into dbg[g][0..7] (never used for results).
+//
+// Code-generation notes (gfx950, ROCm 7.2): the column loop is unrolled by 8 through a
+// templated step so that every register-tile index is a compile-time constant (a
+// `switch` on the column made hipcc shuffle the tile through AGPRs: 1.3k v_accvgpr and
+// 370 branches, 5 us per column); conditionals on per-row state are selects, not
+// branches; the tile is RT x 8 with RT = 4 so the whole state stays in arch VGPRs.
+template <typename T, int RT, bool DBG>
 __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__restrict__ P, int ldp,
                                                             int row0, int col0,
                                                             int32_t *__restrict__ ipiv,
                                                             int *__restrict__ info, XHdr *hdr,
-                                                            T *xrow, int *status) {
+                                                            XGran *xrow, int *status,
+                                                            unsigned long long *dbg) {
     constexpr int RB = 16 * RT;
     __shared__ T s_col[2][RB];
-    __shared__ double s_cv[2][16];
-    __shared__ int s_ci[2][16];
+    __shared__ double s_cv[16];
+    __shared__ int s_ci[16];
     __shared__ __attribute__((aligned(16))) T s_u[PC_COLS];
     __shared__ int s_win[4];      // [0]=winner workgroup, [1]=winner row (panel-local), [2]=valid
+    __shared__ int s_hist[PC_COLS];           // winner row of every column (for the swap replay)
     __shared__ int s_topid[PC_COLS], s_postop[PC_COLS];
     __shared__ int s_order[RB];
 
@@ -69,26 +95,29 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
     const int lane = tid & 63, wave = tid >> 6;
     const int base = g * RB;
 
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+#define STAMP(i)                                                              \
+    if (DBG && wave == 0) {                                                   \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();      \
+        seg[i] += tn_ - tlast;                                                \
+        tlast = tn_;                                                          \
+    }
+
     // buffer descriptors for the exchange area (sc1 traffic only)
     __amdgpu_buffer_rsrc_t r_hdr =
-        __builtin_amdgcn_make_buffer_rsrc(hdr, 0, 2 * G * (int)sizeof(XHdr), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(hdr, 0, 2 * G * HDR_STRIDE, 0x00020000);
     __amdgpu_buffer_rsrc_t r_row =
-        __builtin_amdgcn_make_buffer_rsrc(xrow, 0, 2 * G * PC_COLS * (int)sizeof(T), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(xrow, 0, 2 * G * PC_COLS * (int)sizeof(XGran), 0x00020000);
 
     // ---- load the slice (rows >= m and columns >= jb read as zero)
     T a[RT][8];
-    const bool vec_ok = (jb == PC_COLS) && ((ldp * sizeof(T)) % 16 == 0) && (((size_t)P) % 16 == 0);
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int gi = base + 16 * r + ty;
         const T *src = P + (size_t)gi * ldp + 8 * tx;
-        if (gi < m && vec_ok) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) a[r][c] = src[c];
-        } else {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
-        }
+        for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
     }
     for (int t = tid; t < PC_COLS; t += 256) { s_topid[t] = t; s_postop[t] = t; }
     for (int t = tid; t < RB; t += 256) s_order[t] = -1;
@@ -97,113 +126,155 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
     for (int r = 0; r < RT; ++r)
         if (base + 16 * r + ty >= m) frozen |= 1u << r;
     bool failed = false;
+    // deferred rank-1 update of the previous column: a[r][c] -= lp[r] * up[c]
+    T lp[RT], up[8];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) lp[r] = T(0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) up[c] = T(0);
     __syncthreads();
 
-    for (int j = 0; j < jb; ++j) {
+    // replay of interchange jj on the position maps (one lane; LAPACK order bookkeeping)
+    auto replay = [&](int jj) {
+        const int c = s_hist[jj] & 0x3fffffff;
+        const bool zero_piv = (s_hist[jj] >> 30) & 1;
+        const int p = (c < jb) ? s_postop[c] : c;
+        const int d = s_topid[jj];
+        if (p != jj) {
+            s_topid[jj] = c;
+            if (p < jb) s_topid[p] = d;
+            s_postop[d] = p;
+            if (c < jb) s_postop[c] = jj;
+        }
+        if (g == 0) {
+            ipiv[jj] = row0 + p;
+            if (zero_piv && info && *info == 0) *info = col0 + jj + 1;
+        }
+    };
+
+    // one column; JC = j & 7 is a compile-time constant
+    auto column = [&](auto JCt, const int j) {
+        constexpr int JC = decltype(JCt)::value;
         const int par = j & 1;
         const int jt = j >> 3;
-        const int jc = __builtin_amdgcn_readfirstlane(j & 7);
-        // ---------------- A: column j to LDS + per-thread-row candidates
+        // ---------------- 1: column j up to date, to LDS, per-thread-row candidates
         if (tx == jt) {
-            T colv[RT];
-            switch (jc) {
-#define PICK(k) case k: _Pragma("unroll") for (int r = 0; r < RT; ++r) colv[r] = a[r][k]; break;
-                PICK(0) PICK(1) PICK(2) PICK(3) PICK(4) PICK(5) PICK(6) PICK(7)
-#undef PICK
-            }
             double bv = -1.0;
             int bi = 0x7fffffff;
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                s_col[par][16 * r + ty] = colv[r];
-                const double av = fabs((double)colv[r]);
+                a[r][JC] -= lp[r] * up[JC];
+                const T v = a[r][JC];
+                s_col[par][16 * r + ty] = v;
+                const double av = fabs((double)v);
                 const int gi = base + 16 * r + ty;
-                if (!((frozen >> r) & 1u) && (av > bv || (av == bv && gi < bi))) { bv = av; bi = gi; }
+                const bool better = (((frozen >> r) & 1u) == 0u) & ((av > bv) | ((av == bv) & (gi < bi)));
+                bv = better ? av : bv;
+                bi = better ? gi : bi;
             }
-            s_cv[par][ty] = bv;
-            s_ci[par][ty] = bi;
+            up[JC] = T(0);
+            s_cv[ty] = bv;
+            s_ci[ty] = bi;
         }
+        STAMP(0)
         __syncthreads();
+        STAMP(1)
         // every wave reduces the 16 thread-row candidates to the workgroup's candidate
-        double wv = s_cv[par][lane & 15];
-        int wi = s_ci[par][lane & 15];
+        double wv = s_cv[lane & 15];
+        int wi = s_ci[lane & 15];
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
             const double ov = __shfl_xor(wv, off, 64);
             const int oi = __shfl_xor(wi, off, 64);
-            if (ov > wv || (ov == wv && oi < wi)) { wv = ov; wi = oi; }
+            const bool better = (ov > wv) | ((ov == wv) & (oi < wi));
+            wv = better ? ov : wv;
+            wi = better ? oi : wi;
         }
         const bool have = wv >= 0.0;
         const int cl = have ? wi - base : 0;          // slice-local row of the candidate
         const int cty = cl & 15;
         const int cr = __builtin_amdgcn_readfirstlane(cl >> 4);
-        // ---------------- B: publish (the wave that holds the candidate row; wave 0 if none)
-        const int pub_wave = have ? (cty >> 2) : 0;
+        // ---------------- 2: publish (the wave that holds the candidate row; wave 0 if none)
+        const int pub_wave = __builtin_amdgcn_readfirstlane(have ? (cty >> 2) : 0);
         if (wave == pub_wave) {
             if (have && ty == cty) {
                 T rowv[8];
-                switch (cr) {
-#define PICKR(k) case k: _Pragma("unroll") for (int c = 0; c < 8; ++c) rowv[c] = a[k < RT ? k : 0][c]; break;
-                    PICKR(0) PICKR(1) PICKR(2) PICKR(3) PICKR(4) PICKR(5) PICKR(6) PICKR(7)
-                    PICKR(8) PICKR(9) PICKR(10) PICKR(11) PICKR(12) PICKR(13) PICKR(14) PICKR(15)
-#undef PICKR
-                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) rowv[c] = T(0);
+#pragma unroll
+                for (int k = 0; k < RT; ++k)
+                    if (cr == k) {  // scalar condition: one of RT short blocks runs
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) rowv[c] = a[k][c] - lp[k] * up[c];
+                    }
                 if (G == 1) {
 #pragma unroll
                     for (int c = 0; c < 8; ++c) s_u[8 * tx + c] = rowv[c];
                 } else {
-                    const int off = ((par * G + g) * PC_COLS + 8 * tx) * (int)sizeof(T);
-                    if (sizeof(T) == 8) {
+                    const int off = ((par * G + g) * PC_COLS + 8 * tx) * (int)sizeof(XGran);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            u4 v;
-                            const unsigned long long b0 = (unsigned long long)__double_as_longlong((double)rowv[2 * q]);
-                            const unsigned long long b1 = (unsigned long long)__double_as_longlong((double)rowv[2 * q + 1]);
-                            v.x = (unsigned)b0; v.y = (unsigned)(b0 >> 32); v.z = (unsigned)b1; v.w = (unsigned)(b1 >> 32);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, r_row, off + 16 * q, 0, 16);
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            u4 v;
-                            v.x = __float_as_uint((float)rowv[4 * q]); v.y = __float_as_uint((float)rowv[4 * q + 1]);
-                            v.z = __float_as_uint((float)rowv[4 * q + 2]); v.w = __float_as_uint((float)rowv[4 * q + 3]);
-                            __builtin_amdgcn_raw_buffer_store_b128(v, r_row, off + 16 * q, 0, 16);
-                        }
+                    for (int c = 0; c < 8; ++c) {
+                        unsigned long long bits;
+                        if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)rowv[c]);
+                        else bits = (unsigned long long)__float_as_uint((float)rowv[c]);
+                        u4 v;
+                        v.x = (unsigned)bits; v.y = (unsigned)(bits >> 32); v.z = (unsigned)(j + 1); v.w = 0u;
+                        __builtin_amdgcn_raw_buffer_store_b128(v, r_row, off + 16 * c, 0, 16);
                     }
                 }
             }
-            if (G > 1) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // row is out before the header
-                if (lane == (have ? ((cty & 3) * 16) : 0)) {
-                    const double hv = have ? wv : -1.0;
-                    const unsigned long long vb = (unsigned long long)__double_as_longlong(hv);
-                    u4 h;
-                    h.x = (unsigned)vb; h.y = (unsigned)(vb >> 32);
-                    h.z = (unsigned)(have ? wi : -1);
-                    h.w = ((unsigned)(j + 1) << 16) | fold16(hv);
-                    __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, (par * G + g) * (int)sizeof(XHdr), 0, 16);
-                }
+            if (G > 1 && lane == (have ? ((cty & 3) * 16) : 0)) {
+                const double hv = have ? wv : -1.0;
+                const unsigned long long vb = (unsigned long long)__double_as_longlong(hv);
+                u4 h;
+                h.x = (unsigned)vb; h.y = (unsigned)(vb >> 32);
+                h.z = (unsigned)(have ? wi : -1);
+                h.w = ((unsigned)(j + 1) << 16) | fold16(hv);
+                __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, (par * G + g) * HDR_STRIDE, 0, 16);
             }
         }
-        if (G == 1) {
-            if (tid == 0) { s_win[0] = 0; s_win[1] = have ? wi : -1; s_win[2] = have ? 1 : 0; }
+        if (G == 1 && tid == 0) { s_win[0] = 0; s_win[1] = have ? wi : -1; s_win[2] = have ? 1 : 0; }
+        STAMP(2)
+        // ---------------- 3: deferred bulk update of column j-1, under the exchange latency
+        if (tx >= jt) {  // up[] is zero for columns <= j-1
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[r][c] -= lp[r] * up[c];
         }
-        // ---------------- C: wave 0 gathers all candidates, picks the winner, fetches its row
+        if (tid == 64 && j > 0) replay(j - 1);
+        STAMP(3)
+        // ---------------- 4: wave 0 gathers all candidates, picks the winner, fetches its row
         if (wave == 0 && G > 1) {
             double bv = -2.0;
             int bi = 0x7fffffff, bg = 0;
-            for (int q = lane; q < G && !failed; q += 64) {
-                int spins = 0;
-                for (;;) {
-                    const u4 h = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, (par * G + q) * (int)sizeof(XHdr), 0, 16);
-                    const double hv = __longlong_as_double((long long)(((unsigned long long)h.y << 32) | h.x));
-                    if ((h.w >> 16) == (unsigned)(j + 1) && (h.w & 0xffffu) == fold16(hv)) {
-                        const int hi = (int)h.z;
-                        if (hi >= 0 && (hv > bv || (hv == bv && hi < bi))) { bv = hv; bi = hi; bg = q; }
-                        break;
+            // lane q watches headers q, q+64, q+128, q+192: all of them in flight per poll round
+            unsigned pend = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k < G) pend |= 1u << k;
+            int spins = 0;
+            while (pend && !failed) {
+                u4 h[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((pend >> k) & 1u)
+                        h[k] = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, (par * G + lane + 64 * k) * HDR_STRIDE, 0, 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((pend >> k) & 1u) {
+                        const double hv = __longlong_as_double((long long)(((unsigned long long)h[k].y << 32) | h[k].x));
+                        if ((h[k].w >> 16) == (unsigned)(j + 1) && (h[k].w & 0xffffu) == fold16(hv)) {
+                            const int hi = (int)h[k].z;
+                            const bool better = (hi >= 0) & ((hv > bv) | ((hv == bv) & (hi < bi)));
+                            bv = better ? hv : bv;
+                            bi = better ? hi : bi;
+                            bg = better ? lane + 64 * k : bg;
+                            pend &= ~(1u << k);
+                        }
                     }
-                    if (++spins > SPIN_LIMIT) { failed = true; break; }
+                if (pend) {
+                    if (++spins > SPIN_LIMIT) failed = true;
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
@@ -212,16 +283,32 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
                 const double ov = __shfl_xor(bv, off, 64);
                 const int oi = __shfl_xor(bi, off, 64);
                 const int og = __shfl_xor(bg, off, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; bg = og; }
+                const bool better = (ov > bv) | ((ov == bv) & (oi < bi));
+                bv = better ? ov : bv;
+                bi = better ? oi : bi;
+                bg = better ? og : bg;
             }
             const bool valid = bv >= 0.0;
-            if (valid) {
-                // winner's row: 64 lanes x 16 B covers 128 fp64 (fp32: lanes 0..31)
-                const int nl = (int)(PC_COLS * sizeof(T) / 16);
-                if (lane < nl) {
-                    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(
-                        r_row, (par * G + bg) * PC_COLS * (int)sizeof(T) + 16 * lane, 0, 16);
-                    *((u4 *)((char *)s_u + 16 * lane)) = v;
+            STAMP(4)
+            if (valid && !failed) {
+                // winner's row: 128 granules, two per lane, re-read until both tags match
+                const int roff = (par * G + bg) * PC_COLS * (int)sizeof(XGran);
+                int spins = 0;
+                for (;;) {
+                    const u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * lane, 0, 16);
+                    const u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * (lane + 64), 0, 16);
+                    if (v0.z == (unsigned)(j + 1) && v1.z == (unsigned)(j + 1)) {
+                        if (sizeof(T) == 8) {
+                            s_u[lane] = (T)__longlong_as_double((long long)(((unsigned long long)v0.y << 32) | v0.x));
+                            s_u[lane + 64] = (T)__longlong_as_double((long long)(((unsigned long long)v1.y << 32) | v1.x));
+                        } else {
+                            s_u[lane] = (T)__uint_as_float(v0.x);
+                            s_u[lane + 64] = (T)__uint_as_float(v1.x);
+                        }
+                        break;
+                    }
+                    if (++spins > SPIN_LIMIT) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
             if (lane == 0) { s_win[0] = bg; s_win[1] = valid ? bi : -1; s_win[2] = valid ? 1 : 0; }
@@ -230,96 +317,110 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
                 if (lane == 0) atomicExch(status, 1);
             }
         }
+        STAMP(5)
         __syncthreads();
-        // ---------------- bookkeeping + D: update
+        STAMP(6)
+        // ---------------- 5: multipliers of column j; (l, u) become the next deferred update
         const int wrow = s_win[1];
         const bool valid = s_win[2] != 0;
-        if (!valid) continue;  // no row left (cannot happen for m >= jb); uniform
-        const T piv = s_u[j];
-        if (tid == 0) {
-            // replay the interchange (top position j <-> current position of the winner)
-            const int c = wrow;
-            const int p = (c < jb) ? s_postop[c] : c;
-            const int d = s_topid[j];
-            if (p != j) {
-                s_topid[j] = c;
-                if (p < jb) s_topid[p] = d;
-                s_postop[d] = p;
-                if (c < jb) s_postop[c] = j;
-            }
-            if (g == 0) {
-                ipiv[j] = row0 + p;
-                if (piv == T(0) && info && *info == 0) *info = col0 + j + 1;
-            }
-        }
-        if (s_win[0] == g) {
+        const T piv = valid ? s_u[j] : T(0);
+        if (tid == 0) s_hist[j] = valid ? (wrow | ((piv == T(0)) ? (1 << 30) : 0)) : j;
+        if (valid && s_win[0] == g) {
             const int wl = wrow - base;
             if (ty == (wl & 15)) {
                 frozen |= 1u << (wl >> 4);
                 if (tx == 0) s_order[wl] = j;
             }
         }
-        if (piv != T(0)) {
-            const T rinv = T(1) / piv;
-            T l[RT], u[8];
+        const bool act = valid & (piv != T(0));
+        const T rinv = act ? T(1) / piv : T(0);
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
-                l[r] = ((frozen >> r) & 1u) ? T(0) : s_col[par][16 * r + ty] * rinv;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) u[c] = (8 * tx + c > j) ? s_u[8 * tx + c] : T(0);
-            if (tx == jt) {
-                switch (jc) {
-#define PUT(k) case k: _Pragma("unroll") for (int r = 0; r < RT; ++r) if (!((frozen >> r) & 1u)) a[r][k] = l[r]; break;
-                    PUT(0) PUT(1) PUT(2) PUT(3) PUT(4) PUT(5) PUT(6) PUT(7)
-#undef PUT
-                }
-            }
-            if (tx >= jt) {
-#pragma unroll
-                for (int r = 0; r < RT; ++r)
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) a[r][c] -= l[r] * u[c];
-            }
+        for (int r = 0; r < RT; ++r) {
+            const T v = s_col[par][16 * r + ty] * rinv;
+            lp[r] = ((frozen >> r) & 1u) ? T(0) : v;
         }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const T v = s_u[8 * tx + c];
+            up[c] = (act & (8 * tx + c > j)) ? v : T(0);
+        }
+        if (tx == jt) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r][JC] = (act & (((frozen >> r) & 1u) == 0u)) ? lp[r] : a[r][JC];
+        }
+        STAMP(7)
+    };
+
+    if (DBG) tlast = __builtin_amdgcn_s_memrealtime();
+    for (int j0 = 0; j0 < jb; j0 += 8) {
+#define COL(k) if (j0 + k < jb) column(std::integral_constant<int, k>{}, j0 + k);
+        COL(0) COL(1) COL(2) COL(3) COL(4) COL(5) COL(6) COL(7)
+#undef COL
     }
+    if (DBG && tid == 0)
+        for (int i = 0; i < 8; ++i) dbg[g * 8 + i] = seg[i];
+#undef STAMP
+    // the last column's deferred update touches only columns > jb-1: nothing left inside the panel
+    __syncthreads();
+    if (tid == 0) replay(jb - 1);
     __syncthreads();
     // ---- every row straight to its final (LAPACK-order) position
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         const int lr = 16 * r + ty;
         const int gi = base + lr;
-        if (gi >= m) continue;
-        const int ord = s_order[lr];
-        const int dest = ord >= 0 ? ord : (gi < jb ? s_postop[gi] : gi);
-        T *dst = P + (size_t)dest * ldp + 8 * tx;
+        if (gi < m) {
+            const int ord = s_order[lr];
+            const int dest = ord >= 0 ? ord : (gi < jb ? s_postop[gi] : gi);
+            T *dst = P + (size_t)dest * ldp + 8 * tx;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            if (8 * tx + c < jb) dst[c] = a[r][c];
+            for (int c = 0; c < 8; ++c)
+                if (8 * tx + c < jb) dst[c] = a[r][c];
+        }
     }
 }
 
-template <typename T>
-int panel_cooperative(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0,
-                      int32_t *d_ipiv, int *d_info) {
-    constexpr int RT = 8, RB = 16 * RT;
-    const int G = (m + RB - 1) / RB;
-    if (jb > PC_COLS || G > h->num_cu) return 1;  // caller falls back to the per-column path
-    // exchange area in scratch: status | headers[2][G] | rows[2][G][128]
-    const size_t hdr_bytes = (size_t)2 * G * sizeof(XHdr);
-    const size_t need = 256 + hdr_bytes + (size_t)2 * G * PC_COLS * sizeof(T);
-    if (need > h->scratch_bytes) {
-        set_error("panel_coop: scratch too small (%zu > %zu)", need, h->scratch_bytes);
+template <typename T, int RT>
+static int panel_coop_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp, int row0, int col0,
+                             int32_t *d_ipiv, int *d_info) {
+    // exchange area in scratch: status | headers[2][G] (HDR_STRIDE apart) | granule rows[2][G][128]
+    const size_t hdr_bytes = (size_t)2 * G * HDR_STRIDE;
+    const size_t need = 256 + hdr_bytes + (size_t)2 * G * PC_COLS * sizeof(XGran);
+    const size_t dbg_off = (need + 255) & ~(size_t)255;
+    if (dbg_off + (h->panel_debug ? (size_t)G * 64 : 0) > h->scratch_bytes) {
+        set_error("panel_coop: scratch too small (%zu > %zu)", dbg_off, h->scratch_bytes);
         return LSX_ERR_INTERNAL;
     }
     int *status = (int *)h->scratch;
     XHdr *hdr = (XHdr *)((char *)h->scratch + 256);
-    T *xrow = (T *)((char *)h->scratch + 256 + hdr_bytes);
-    // headers (and the status word) are zeroed before EVERY launch: epoch 0 never matches
-    LSX_HIP(hipMemsetAsync(h->scratch, 0, 256 + hdr_bytes, h->stream));
-    hipLaunchKernelGGL((panel_coop_kernel<T, RT>), dim3(G), dim3(256), 0, h->stream, m, jb, P, ldp, row0,
-                       col0, d_ipiv, d_info, hdr, xrow, status);
+    XGran *xrow = (XGran *)((char *)h->scratch + 256 + hdr_bytes);
+    // status word, headers AND granules are zeroed before EVERY launch: epoch 0 never matches
+    LSX_HIP(hipMemsetAsync(h->scratch, 0, need, h->stream));
+    if (h->panel_debug) {
+        unsigned long long *dbg = (unsigned long long *)((char *)h->scratch + dbg_off);
+        hipLaunchKernelGGL((panel_coop_kernel<T, RT, true>), dim3(G), dim3(256), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg);
+    } else {
+        hipLaunchKernelGGL((panel_coop_kernel<T, RT, false>), dim3(G), dim3(256), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, (unsigned long long *)nullptr);
+    }
     LSX_HIP(hipGetLastError());
     return LSX_OK;
+}
+
+// Returns 1 when the shape is outside what the cooperative kernel supports (caller falls back).
+template <typename T>
+int panel_cooperative(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0,
+                      int32_t *d_ipiv, int *d_info) {
+    if (jb > PC_COLS) return 1;
+    // rows per thread: 4 (64-row slices) unless that needs more workgroups than CUs or the
+    // caller asked for the larger tile; every workgroup must be resident at once
+    int rt = h->panel_rt;
+    if ((m + 63) / 64 > h->num_cu) rt = 8;
+    const int G = (m + 16 * rt - 1) / (16 * rt);
+    if (G > h->num_cu) return 1;
+    if (rt == 8) return panel_coop_launch<T, 8>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+    return panel_coop_launch<T, 4>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
 }
 
 template int panel_cooperative<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);

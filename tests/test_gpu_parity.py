@@ -127,10 +127,16 @@ def _plu_residual(A, LU, ipiv):
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 16, 17, 63, 64, 65, 100, 128, 129, 200, 256, 300, 511, 640, 1000])
 def test_getrf_matches_cpu_twin(la, n):
+    """panel mode 0: two launches per column (the simple fallback path)."""
     from linalg_solver_amd import dense, gen
 
     A, b = gen.system(gen.U11, 100 + n, n)
-    LU, ipiv, info = dense.lu_factor(A)
+    h = la.default_handle()
+    h.set_option("panel", 0)
+    try:
+        LU, ipiv, info = dense.lu_factor(A)
+    finally:
+        h.set_option("panel", 1)
     oLU, oipiv, oinfo = capi.getrf(A)
     assert info == oinfo == 0
     assert np.array_equal(ipiv, oipiv), "pivot sequence differs from the partial-pivot twin"
@@ -147,13 +153,21 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     from linalg_solver_amd import dense, gen
 
     h = la.default_handle()
-    h.set_option("panel", 1)
-    try:
-        A, b = gen.system(gen.U11, 500 + n, n)
-        LU, ipiv, info = dense.lu_factor(A)
-    finally:
-        h.set_option("panel", 0)
+    A, b = gen.system(gen.U11, 500 + n, n)
     oLU, oipiv, oinfo = capi.getrf(A)
+    results = []
+    try:
+        for rt, look in ((4, 1), (8, 1), (4, 0)):
+            h.set_option("panel", 1)
+            h.set_option("panel_rt", rt)
+            h.set_option("lookahead", look)
+            results.append(dense.lu_factor(A))
+    finally:
+        h.set_option("panel_rt", 4)
+        h.set_option("lookahead", 0)
+    for LU2, ipiv2, info2 in results[1:]:  # tile height and look-ahead do not change a single bit
+        assert info2 == 0 and np.array_equal(ipiv2, results[0][1]) and np.array_equal(LU2, results[0][0])
+    LU, ipiv, info = results[0]
     assert info == oinfo == 0
     assert np.array_equal(ipiv, oipiv), "pivot sequence differs from the partial-pivot twin"
     assert np.max(np.abs(np.tril(LU, -1))) <= 1.0
@@ -171,14 +185,14 @@ def test_getrf_cooperative_panel_integer_and_singular(la, n):
         A, _ = gen.system(gen.INT5, 60 + n, n)
         LU, ipiv, info = dense.lu_factor(A)
         S = A.copy()
-        S[:, 5] = S[:, 2]  # exactly singular
+        S[:, 5] = 0.0  # a zero column stays exactly zero: both sides must report column 6
         _, _, sinfo = dense.lu_factor(S)
         LU32, ipiv32, info32 = dense.lu_factor(A.astype(np.float32), dtype=np.float32)
     finally:
-        h.set_option("panel", 0)
+        h.set_option("panel", 1)
     assert info == 0 and _plu_residual(A, LU, ipiv) < 50 * n * 2.3e-16
     assert np.max(np.abs(np.tril(LU, -1))) <= 1.0
-    assert sinfo == capi.getrf(S)[2] > 0
+    assert sinfo == capi.getrf(S)[2] == 6
     assert info32 == 0 and _plu_residual(A, LU32.astype(np.float64), ipiv32) < 1e-4
 
 
