@@ -85,6 +85,14 @@ struct Carver {
 
 static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// row interchanges of the panel that was just factored, applied to `ncols` columns at Acols
+template <typename T>
+static int apply_panel_swaps(lsx_handle_t h, int ncols, T *Acols, int lda, int row0, int jb,
+                             const int32_t *d_ipiv) {
+    if (h->moves_valid) return launch_laswp_moves<T>(h, ncols, Acols, lda, row0);
+    return launch_laswp<T>(h, ncols, Acols, lda, row0, jb, d_ipiv);
+}
+
 // ---------------------------------------------------------------- look-ahead LU driver
 // Right-looking LU with look-ahead depth 1.  The update of step k is split: the columns of
 // the NEXT panel are updated first, then that panel is factored on the high-priority side
@@ -116,13 +124,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         const int jb = (n - k < nb) ? n - k : nb;
         T *Akk = A + (size_t)k * lda + k;
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));  // panel k is factored
-        LSX_TRY(launch_laswp<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
         const int rest = n - k - jb;
         if (rest <= 0) break;
         T *A12 = A + (size_t)k * lda + k + jb;
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
-        LSX_TRY(launch_laswp<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
+        LSX_TRY(apply_panel_swaps<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
         LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
         LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Tinv, A12, lda));
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
@@ -148,25 +156,42 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     const int nb = h->nb;
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
-                                  ((size_t)n / 64 + 2) * 5248 + 8192));
-    const size_t tinv_elems = (size_t)((nb + 63) / 64) * 64 * 64;
+                                  ((size_t)n / 32 + 2) * 5248 + 8192));
+    const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
     T *Tinv = (T *)h->ws2;
     if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
     if (h->lookahead && n > 2 * nb) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv);
-    for (int k = 0; k < n; k += nb) {
-        const int jb = (n - k < nb) ? n - k : nb;
-        T *Akk = A + (size_t)k * lda + k;
-        LSX_TRY(launch_panel<T>(h, n - k, jb, Akk, lda, k, d_ipiv + k, d_info));
-        LSX_TRY(launch_laswp<T>(h, k, A, lda, k, jb, d_ipiv + k));
-        const int rest = n - k - jb;
+    // Two-level blocking: `kb` panels of width nb are factored back to back (each one updating
+    // only the remaining columns of its own super-block), then ONE trailing update of depth
+    // K = kb*nb follows.  The MFMA update moves C once per K: K = 256 halves its HBM traffic.
+    const int W = nb * h->kblock;
+    for (int k = 0; k < n; k += W) {
+        const int w = (n - k < W) ? n - k : W;  // width of this super-block
+        for (int j = 0; j < w; j += nb) {
+            const int c = k + j;                      // first column of this panel
+            const int jb = (w - j < nb) ? w - j : nb;
+            T *Acc = A + (size_t)c * lda + c;
+            LSX_TRY(launch_panel<T>(h, n - c, jb, Acc, lda, c, d_ipiv + c, d_info));
+            LSX_TRY(apply_panel_swaps<T>(h, c, A, lda, c, jb, d_ipiv + c));                      // left
+            LSX_TRY(apply_panel_swaps<T>(h, n - c - jb, A + c + jb, lda, c, jb, d_ipiv + c));  // right
+            const int inner = w - j - jb;  // columns of the super-block still to be factored
+            if (inner > 0) {
+                T *A12 = A + (size_t)c * lda + c + jb;
+                LSX_TRY(launch_trtri<T>(h, 1, jb, Acc, lda, Tinv));
+                LSX_TRY(launch_trsm_block<T>(h, 1, jb, inner, Acc, lda, Tinv, A12, lda));
+                LSX_TRY(launch_gemm_sub<T>(h, n - c - jb, inner, jb, A + (size_t)(c + jb) * lda + c, lda, A12,
+                                           lda, A + (size_t)(c + jb) * lda + c + jb, lda));
+            }
+        }
+        const int rest = n - k - w;
         if (rest > 0) {
-            T *A12 = A + (size_t)k * lda + k + jb;
-            LSX_TRY(launch_laswp<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
-            LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
-            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Tinv, A12, lda));
-            LSX_TRY(launch_gemm_sub<T>(h, rest, rest, jb, A + (size_t)(k + jb) * lda + k, lda, A12, lda,
-                                       A + (size_t)(k + jb) * lda + k + jb, lda));
+            T *Akk = A + (size_t)k * lda + k;
+            T *A12 = A + (size_t)k * lda + k + w;
+            LSX_TRY(launch_trtri<T>(h, 1, w, Akk, lda, Tinv));
+            LSX_TRY(launch_trsm_block<T>(h, 1, w, rest, Akk, lda, Tinv, A12, lda));
+            LSX_TRY(launch_gemm_sub<T>(h, rest, rest, w, A + (size_t)(k + w) * lda + k, lda, A12, lda,
+                                       A + (size_t)(k + w) * lda + k + w, lda));
         }
     }
     return LSX_OK;
@@ -380,6 +405,10 @@ int lsx_create(lsx_handle_t *out, int device) {
         }
     }
     int r = grow(&h->scratch, &h->scratch_bytes, 1 << 20);
+    if (r == LSX_OK) {
+        size_t mv = 0;
+        r = grow(&h->moves, &mv, 4096);
+    }
     if (r != LSX_OK) { (void)hipStreamDestroy(h->own_stream); delete h; return r; }
     *out = h;
     return LSX_OK;
@@ -395,6 +424,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->scratch) (void)hipFree(h->scratch);
+    if (h->moves) (void)hipFree(h->moves);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -427,14 +457,20 @@ int lsx_synchronize(lsx_handle_t h) {
 int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     LSX_ARG(h && key);
     if (!strcmp(key, "nb")) {
-        LSX_ARG(value >= 16 && value <= 256 && value % 16 == 0);
+        LSX_ARG(value >= 16 && value <= 128 && value % 16 == 0);
         h->nb = value;
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_mode = value;
+    } else if (!strcmp(key, "kblock")) {
+        LSX_ARG(value == 1 || value == 2);
+        h->kblock = value;
     } else if (!strcmp(key, "panel_rt")) {
-        LSX_ARG(value == 4 || value == 8);
+        LSX_ARG(value == 2 || value == 4 || value == 8);
         h->panel_rt = value;
+    } else if (!strcmp(key, "panel_nt")) {
+        LSX_ARG(value == 256 || value == 512 || value == 1024);
+        h->panel_nt = value;
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
@@ -453,6 +489,8 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "panel")) *value = h->panel_mode;
     else if (!strcmp(key, "lookahead")) *value = h->lookahead;
     else if (!strcmp(key, "panel_rt")) *value = h->panel_rt;
+    else if (!strcmp(key, "kblock")) *value = h->kblock;
+    else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
     return LSX_OK;
@@ -604,7 +642,7 @@ int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int 
 int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,
                       int *d_info) {
     LSX_ARG(h && m >= 1 && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 64 + 2) * 5248 + 8192));
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 32 + 2) * 5248 + 8192));
     return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
 }
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,

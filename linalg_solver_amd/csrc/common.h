@@ -60,10 +60,12 @@ struct lsx_handle_s {
     hipStream_t side_stream = nullptr;  // high-priority stream for the look-ahead panel
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_start = nullptr;
     // tunables
-    int nb = 128;        // panel width
+    int nb = 128;        // panel width (<= 128)
+    int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 1;  // 0 = per-column launches, 1 = cooperative kernel
     int lookahead = 0;   // 1: factor panel k+1 on side_stream under the trailing update of step k
-    int panel_rt = 4;     // rows per thread in the cooperative panel (4 or 8)
+    int panel_rt = 4;     // rows per thread in the cooperative panel
+    int panel_nt = 256;   // threads per workgroup in the cooperative panel
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     int num_cu = 256;
     // persistent device workspace (grown on demand, never shrunk)
@@ -74,6 +76,8 @@ struct lsx_handle_s {
     void *ws3 = nullptr;     // permutation vector + right-hand-side copy
     size_t ws3_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
+    void *moves = nullptr;      // int2[256]: gather list emitted by the cooperative panel kernel
+    bool moves_valid = false;   // set by the last panel launch when `moves` describes its interchanges
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     lsx::Prof prof;
@@ -115,6 +119,9 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
                  int *d_info);
 template <typename T>
 int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, const int32_t *d_ipiv);
+// same interchanges from the gather list h->moves (written by the cooperative panel kernel)
+template <typename T>
+int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
 // Tinv (ceil(jb/64) blocks of 64x64) <- inverses of the 64x64 diagonal blocks of the
 // unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.
 template <typename T>

@@ -126,6 +126,48 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
     return LSX_OK;
 }
 
+// Gather-list form: the cooperative panel kernel already knows every row's final position,
+// so the column chunks only have to move data (no per-workgroup replay of the interchanges).
+template <typename T, int CW>
+__global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
+                                                          const int2 *__restrict__ moves) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *s_dst = (int *)smem;          // 256
+    int *s_src = s_dst + 256;          // 256
+    T *tile = (T *)(smem + 512 * sizeof(int));  // [256][CW]
+    const int tid = threadIdx.x;
+    {
+        const int2 mv = moves[tid];
+        s_dst[tid] = mv.x;
+        s_src[tid] = mv.y;
+    }
+    __syncthreads();
+    const int c0 = blockIdx.x * CW;
+    const int tc = tid % CW, tr = tid / CW;
+    constexpr int RP = 256 / CW;
+    const bool cok = c0 + tc < ncols;
+    for (int d = tr; d < 256; d += RP)
+        if (s_dst[d] >= 0 && cok) tile[d * CW + tc] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
+    __syncthreads();
+    for (int d = tr; d < 256; d += RP)
+        if (s_dst[d] >= 0 && cok) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = tile[d * CW + tc];
+}
+
+template <typename T>
+int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
+    if (ncols <= 0) return LSX_OK;
+    constexpr int CW = 32;
+    ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
+    const size_t shm = 512 * sizeof(int) + (size_t)256 * CW * sizeof(T);
+    if (shm > 48 * 1024)
+        LSX_HIP(hipFuncSetAttribute((const void *)laswp_moves_kernel<T, CW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), shm, h->stream,
+                       ncols, A, lda, row0, (const int2 *)h->moves);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
 // ------------------------------------------------------------------ triangular 64-block inverse
 // One workgroup inverts one 64 x 64 diagonal block of a unit-lower (lower=1) or
 // non-unit upper (lower=0) triangle: 16 x 16 blocks by substitution, then two
@@ -564,6 +606,7 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
 #define INST(T)                                                                                   \
     template int launch_fill<T>(lsx_handle_t, int, uint64_t, int, int, T *, int, int, int);       \
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
+    template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
                                       int);                                                       \

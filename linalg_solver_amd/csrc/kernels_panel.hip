@@ -166,6 +166,7 @@ template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
                  int *d_info) {
     if (m <= 0 || jb <= 0) return LSX_OK;
+    h->moves_valid = false;
     ProfScope ps(h, LSX_PROF_PANEL, 0, 2.0 * sizeof(T) * m * (double)jb);
     // the panel's first column is global column row0 (square LU: panel starts on the diagonal)
     if (h->panel_mode == 1) {

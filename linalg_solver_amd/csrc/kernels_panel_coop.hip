@@ -73,17 +73,19 @@ struct __attribute__((aligned(16))) XGran {
 // `switch` on the column made hipcc shuffle the tile through AGPRs: 1.3k v_accvgpr and
 // 370 branches, 5 us per column); conditionals on per-row state are selects, not
 // branches; the tile is RT x 8 with RT = 4 so the whole state stays in arch VGPRs.
-template <typename T, int RT, bool DBG>
-__global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__restrict__ P, int ldp,
+template <typename T, int RT, int NT, bool DBG>
+__global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb, T *__restrict__ P, int ldp,
                                                             int row0, int col0,
                                                             int32_t *__restrict__ ipiv,
                                                             int *__restrict__ info, XHdr *hdr,
                                                             XGran *xrow, int *status,
-                                                            unsigned long long *dbg) {
-    constexpr int RB = 16 * RT;
+                                                            unsigned long long *dbg,
+                                                            int2 *__restrict__ moves) {
+    constexpr int NTY = NT / 16;   // thread rows
+    constexpr int RB = NTY * RT;   // panel rows per workgroup
     __shared__ T s_col[2][RB];
-    __shared__ double s_cv[16];
-    __shared__ int s_ci[16];
+    __shared__ double s_cv[NTY];
+    __shared__ int s_ci[NTY];
     __shared__ __attribute__((aligned(16))) T s_u[PC_COLS];
     __shared__ int s_win[4];      // [0]=winner workgroup, [1]=winner row (panel-local), [2]=valid
     __shared__ int s_hist[PC_COLS];           // winner row of every column (for the swap replay)
@@ -114,17 +116,17 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
     T a[RT][8];
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        const int gi = base + 16 * r + ty;
+        const int gi = base + NTY * r + ty;
         const T *src = P + (size_t)gi * ldp + 8 * tx;
 #pragma unroll
         for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
     }
-    for (int t = tid; t < PC_COLS; t += 256) { s_topid[t] = t; s_postop[t] = t; }
-    for (int t = tid; t < RB; t += 256) s_order[t] = -1;
+    for (int t = tid; t < PC_COLS; t += NT) { s_topid[t] = t; s_postop[t] = t; }
+    for (int t = tid; t < RB; t += NT) s_order[t] = -1;
     unsigned frozen = 0;  // bit r: local row 16*r+ty already used as a pivot (or outside the panel)
 #pragma unroll
     for (int r = 0; r < RT; ++r)
-        if (base + 16 * r + ty >= m) frozen |= 1u << r;
+        if (base + NTY * r + ty >= m) frozen |= 1u << r;
     bool failed = false;
     // deferred rank-1 update of the previous column: a[r][c] -= lp[r] * up[c]
     T lp[RT], up[8];
@@ -165,9 +167,9 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
             for (int r = 0; r < RT; ++r) {
                 a[r][JC] -= lp[r] * up[JC];
                 const T v = a[r][JC];
-                s_col[par][16 * r + ty] = v;
+                s_col[par][NTY * r + ty] = v;
                 const double av = fabs((double)v);
-                const int gi = base + 16 * r + ty;
+                const int gi = base + NTY * r + ty;
                 const bool better = (((frozen >> r) & 1u) == 0u) & ((av > bv) | ((av == bv) & (gi < bi)));
                 bv = better ? av : bv;
                 bi = better ? gi : bi;
@@ -180,10 +182,11 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
         __syncthreads();
         STAMP(1)
         // every wave reduces the 16 thread-row candidates to the workgroup's candidate
-        double wv = s_cv[lane & 15];
-        int wi = s_ci[lane & 15];
+        constexpr int NCM = NTY < 64 ? NTY : 64;
+        double wv = s_cv[lane & (NCM - 1)];
+        int wi = s_ci[lane & (NCM - 1)];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
+        for (int off = NCM / 2; off > 0; off >>= 1) {
             const double ov = __shfl_xor(wv, off, 64);
             const int oi = __shfl_xor(wi, off, 64);
             const bool better = (ov > wv) | ((ov == wv) & (oi < wi));
@@ -192,8 +195,8 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
         }
         const bool have = wv >= 0.0;
         const int cl = have ? wi - base : 0;          // slice-local row of the candidate
-        const int cty = cl & 15;
-        const int cr = __builtin_amdgcn_readfirstlane(cl >> 4);
+        const int cty = cl % NTY;
+        const int cr = __builtin_amdgcn_readfirstlane(cl / NTY);
         // ---------------- 2: publish (the wave that holds the candidate row; wave 0 if none)
         const int pub_wave = __builtin_amdgcn_readfirstlane(have ? (cty >> 2) : 0);
         if (wave == pub_wave) {
@@ -327,8 +330,8 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
         if (tid == 0) s_hist[j] = valid ? (wrow | ((piv == T(0)) ? (1 << 30) : 0)) : j;
         if (valid && s_win[0] == g) {
             const int wl = wrow - base;
-            if (ty == (wl & 15)) {
-                frozen |= 1u << (wl >> 4);
+            if (ty == (wl % NTY)) {
+                frozen |= 1u << (wl / NTY);
                 if (tx == 0) s_order[wl] = j;
             }
         }
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
         const T rinv = act ? T(1) / piv : T(0);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const T v = s_col[par][16 * r + ty] * rinv;
+            const T v = s_col[par][NTY * r + ty] * rinv;
             lp[r] = ((frozen >> r) & 1u) ? T(0) : v;
         }
 #pragma unroll
@@ -364,10 +367,28 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
     __syncthreads();
     if (tid == 0) replay(jb - 1);
     __syncthreads();
+    // ---- the same permutation as a gather list for the columns outside the panel:
+    // final[row0 + dst] = old[row0 + src]; slot j: pivot j, slot PC_COLS + d: displaced top row d
+    if (g == 0 && moves) {
+        for (int t = tid; t < 2 * PC_COLS; t += NT) {
+            int dst = -1, src = -1;
+            if (t < jb) {
+                dst = t;
+                src = s_hist[t] & 0x3fffffff;
+            } else if (t >= PC_COLS && t - PC_COLS < jb) {
+                const int d = t - PC_COLS;
+                bool is_pivot = false;
+                for (int q = 0; q < jb; ++q) is_pivot |= ((s_hist[q] & 0x3fffffff) == d);
+                if (!is_pivot) { dst = s_postop[d]; src = d; }
+            }
+            if (dst == src) dst = src = -1;
+            moves[t] = make_int2(dst, src);
+        }
+    }
     // ---- every row straight to its final (LAPACK-order) position
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
-        const int lr = 16 * r + ty;
+        const int lr = NTY * r + ty;
         const int gi = base + lr;
         if (gi < m) {
             const int ord = s_order[lr];
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void panel_coop_kernel(int m, int jb, T *__
     }
 }
 
-template <typename T, int RT>
+template <typename T, int RT, int NT>
 static int panel_coop_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp, int row0, int col0,
                              int32_t *d_ipiv, int *d_info) {
     // exchange area in scratch: status | headers[2][G] (HDR_STRIDE apart) | granule rows[2][G][128]
@@ -398,13 +419,15 @@ static int panel_coop_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp
     LSX_HIP(hipMemsetAsync(h->scratch, 0, need, h->stream));
     if (h->panel_debug) {
         unsigned long long *dbg = (unsigned long long *)((char *)h->scratch + dbg_off);
-        hipLaunchKernelGGL((panel_coop_kernel<T, RT, true>), dim3(G), dim3(256), 0, h->stream, m, jb, P, ldp,
-                           row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg);
+        hipLaunchKernelGGL((panel_coop_kernel<T, RT, NT, true>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves);
     } else {
-        hipLaunchKernelGGL((panel_coop_kernel<T, RT, false>), dim3(G), dim3(256), 0, h->stream, m, jb, P, ldp,
-                           row0, col0, d_ipiv, d_info, hdr, xrow, status, (unsigned long long *)nullptr);
+        hipLaunchKernelGGL((panel_coop_kernel<T, RT, NT, false>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, (unsigned long long *)nullptr,
+                           (int2 *)h->moves);
     }
     LSX_HIP(hipGetLastError());
+    h->moves_valid = true;
     return LSX_OK;
 }
 
@@ -413,14 +436,20 @@ template <typename T>
 int panel_cooperative(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0,
                       int32_t *d_ipiv, int *d_info) {
     if (jb > PC_COLS) return 1;
-    // rows per thread: 4 (64-row slices) unless that needs more workgroups than CUs or the
-    // caller asked for the larger tile; every workgroup must be resident at once
-    int rt = h->panel_rt;
-    if ((m + 63) / 64 > h->num_cu) rt = 8;
-    const int G = (m + 16 * rt - 1) / (16 * rt);
+    // shape of a workgroup: NT threads (16 thread-columns x NT/16 thread-rows), RT rows per thread.
+    // More threads with small tiles keep each wave's instruction stream short while halving the
+    // number of workgroups that take part in every exchange; all of them must be resident at once.
+    int nt = h->panel_nt, rt = h->panel_rt;
+    auto rows = [](int nt_, int rt_) { return nt_ / 16 * rt_; };
+    if ((m + rows(nt, rt) - 1) / rows(nt, rt) > h->num_cu) { nt = 512; rt = 8; }  // 256-row slices
+    const int G = (m + rows(nt, rt) - 1) / rows(nt, rt);
     if (G > h->num_cu) return 1;
-    if (rt == 8) return panel_coop_launch<T, 8>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
-    return panel_coop_launch<T, 4>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+#define LSX_PC(RT_, NT_) \
+    if (rt == RT_ && nt == NT_) return panel_coop_launch<T, RT_, NT_>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+    LSX_PC(4, 256) LSX_PC(8, 256) LSX_PC(2, 512) LSX_PC(4, 512) LSX_PC(8, 512) LSX_PC(2, 1024)
+#undef LSX_PC
+    set_error("panel_coop: unsupported workgroup shape nt=%d rt=%d", nt, rt);
+    return LSX_ERR_ARG;
 }
 
 template int panel_cooperative<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);

@@ -157,16 +157,24 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     oLU, oipiv, oinfo = capi.getrf(A)
     results = []
     try:
-        for rt, look in ((4, 1), (8, 1), (4, 0)):
+        for rt, look, kb, nt in ((4, 0, 2, 256), (8, 0, 2, 512), (4, 1, 1, 512), (4, 0, 1, 256), (2, 0, 1, 1024)):
             h.set_option("panel", 1)
             h.set_option("panel_rt", rt)
+            h.set_option("panel_nt", nt)
             h.set_option("lookahead", look)
+            h.set_option("kblock", kb)
             results.append(dense.lu_factor(A))
     finally:
         h.set_option("panel_rt", 4)
+        h.set_option("panel_nt", 256)
         h.set_option("lookahead", 0)
-    for LU2, ipiv2, info2 in results[1:]:  # tile height and look-ahead do not change a single bit
-        assert info2 == 0 and np.array_equal(ipiv2, results[0][1]) and np.array_equal(LU2, results[0][0])
+        h.set_option("kblock", 1)
+    assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])
+    # tile height and look-ahead do not change a single bit
+    assert np.array_equal(results[1][1], results[0][1]) and np.array_equal(results[1][0], results[0][0])
+    assert np.array_equal(results[2][1], results[3][1]) and np.array_equal(results[2][0], results[3][0])
+    # the update depth (K = 128 vs 256) changes summation order only
+    assert np.array_equal(results[3][1], results[0][1]) and relerr(results[3][0], results[0][0]) < 1e-12
     LU, ipiv, info = results[0]
     assert info == oinfo == 0
     assert np.array_equal(ipiv, oipiv), "pivot sequence differs from the partial-pivot twin"

@@ -53,9 +53,10 @@ def main():
                 print(f"gemm_sub {str(dt)[6:]} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
                       f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
     if "panel" in args.what:
-        for mode, rt in ((1, 4), (1, 8), (0, 4)):
+        for mode, nt, rt in ((1, 256, 4), (1, 512, 4), (1, 512, 2), (1, 1024, 2), (1, 512, 8)):
             dev.h.set_option("panel", mode)
             dev.h.set_option("panel_rt", rt)
+            dev.h.set_option("panel_nt", nt)
             for m in (args.n, args.n // 2, args.n // 8, 256):
                 P0 = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
                 dev.fill_(P0, gen.U11, 3)
@@ -69,7 +70,7 @@ def main():
                 tmin, tmed = timeit(run, reps=5, warm=1)
                 tcopy, _ = timeit(lambda: P.copy_(P0), reps=5, warm=1)
                 t = tmin - tcopy
-                print(f"panel mode={mode} rt={rt} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)  "
+                print(f"panel mode={mode} nt={nt} rt={rt} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)  "
                       f"{2 * 8 * m * args.nb / t / 1e6:.1f} GB/s", flush=True)
     if "stamps" in args.what:
         import numpy as np
@@ -77,8 +78,10 @@ def main():
                  "4b:row granules", "barrier C", "5:multipliers"]
         dev.h.set_option("panel", 1)
         dev.h.set_option("panel_debug", 1)
-        for rt, m in ((4, args.n), (8, args.n), (4, 1024), (8, 1024), (4, 128)):
+        for nt, rt, m in ((256, 4, args.n), (512, 4, args.n), (512, 2, args.n), (1024, 2, args.n), (512, 8, args.n),
+                          (512, 4, 1024), (1024, 2, 1024)):
             dev.h.set_option("panel_rt", rt)
+            dev.h.set_option("panel_nt", nt)
             P = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
             ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
             info = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -86,12 +89,12 @@ def main():
                 dev.fill_(P, gen.U11, 3)
                 dev.panel_(P, 0, ipiv, info)
             torch.cuda.synchronize()
-            G = (m + 16 * rt - 1) // (16 * rt)
+            G = (m + nt // 16 * rt - 1) // (nt // 16 * rt)
             need = 256 + 2 * G * 512 + 2 * G * 128 * 16
             off = (need + 255) & ~255
             raw = np.frombuffer(dev.h.read_scratch(off, G * 64), dtype=np.uint64).reshape(G, 8).astype(np.float64)
             us = raw / 100.0 / args.nb  # 100 MHz ticks -> us per column
-            print(f"stamps rt={rt} m={m} G={G}: per-column us (mean over WGs | max)   total {us.sum(1).mean():.2f}")
+            print(f"stamps nt={nt} rt={rt} m={m} G={G}: per-column us (mean over WGs | max)   total {us.sum(1).mean():.2f}")
             for i, nm in enumerate(names):
                 print(f"   {nm:22s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
         dev.h.set_option("panel_debug", 0)
@@ -102,8 +105,11 @@ def main():
         A = A0.clone()
         ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        for mode, rt, look, nb in ((1, 4, 1, 128), (1, 8, 1, 128), (1, 4, 0, 128), (1, 4, 1, 64), (0, 4, 0, 128)):
+        dev.h.set_option("panel_nt", 256)
+        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 2), (1, 4, 0, 128, 1), (1, 4, 1, 128, 1), (1, 4, 0, 64, 2),
+                                       (0, 4, 0, 128, 2)):
             if True:
+                dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
                 dev.h.set_option("panel_rt", rt)
                 dev.h.set_option("lookahead", look)
@@ -118,7 +124,7 @@ def main():
                 dev.h.prof_reset(); dev.h.prof_enable(True); run(); torch.cuda.synchronize()
                 dev.h.prof_enable(False)
                 pr = dev.h.prof_read()
-                print(f"getrf n={n} panel={mode} rt={rt} lookahead={look} nb={nb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
+                print(f"getrf n={n} panel={mode} rt={rt} lookahead={look} nb={nb} kblock={kb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
                       + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()), flush=True)
 
 
