@@ -171,7 +171,8 @@ int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, d
 
 /* Diagnostics: sustained MFMA rate of a register-resident loop (synchronous).
  * is_f32 = 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f32_16x16x4_f32. */
-int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops);
+int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops,
+                       double *clock_mhz /* fp64 only: median in-kernel shader clock, may be NULL */);
 /* Copy a piece of the handle's device scratch to the host (stamped diagnostic builds). */
 int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes);
 

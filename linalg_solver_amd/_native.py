@@ -61,7 +61,7 @@ _SIGS = {
     "lsx_gemm_sub_f32_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
     "lsx_fill_f64_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
-    "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp],
+    "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp, _dp],
     "lsx_diag_read_scratch": [_vp, C.c_size_t, _vp, C.c_size_t],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],
@@ -162,10 +162,12 @@ class Handle:
     def synchronize(self):
         check(self.lib.lsx_synchronize(self._h), "lsx_synchronize")
 
-    def mfma_peak(self, is_f32: bool = False, iters: int = 20000, blocks_per_cu: int = 1) -> float:
-        t = C.c_double(0)
-        check(self.lib.lsx_diag_mfma_peak(self._h, 1 if is_f32 else 0, iters, blocks_per_cu, C.byref(t)))
-        return t.value
+    def mfma_peak(self, is_f32: bool = False, iters: int = 20000, blocks_per_cu: int = 1):
+        """(sustained TFLOP/s, median in-kernel shader clock in MHz [fp64 only, else 0])."""
+        t, c = C.c_double(0), C.c_double(0)
+        check(self.lib.lsx_diag_mfma_peak(self._h, 1 if is_f32 else 0, iters, blocks_per_cu, C.byref(t),
+                                          C.byref(c)))
+        return t.value, c.value
 
     def read_scratch(self, offset: int, nbytes: int) -> bytes:
         buf = C.create_string_buffer(nbytes)

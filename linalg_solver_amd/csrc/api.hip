@@ -462,6 +462,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_mode = value;
+    } else if (!strcmp(key, "gemm_waves")) {
+        LSX_ARG(value == 0 || value == 4 || value == 8);
+        h->gemm_waves = value;
     } else if (!strcmp(key, "kblock")) {
         LSX_ARG(value == 1 || value == 2);
         h->kblock = value;
@@ -490,6 +493,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "lookahead")) *value = h->lookahead;
     else if (!strcmp(key, "panel_rt")) *value = h->panel_rt;
     else if (!strcmp(key, "kblock")) *value = h->kblock;
+    else if (!strcmp(key, "gemm_waves")) *value = h->gemm_waves;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
@@ -687,9 +691,10 @@ int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes
     return LSX_OK;
 }
 
-int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops) {
+int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops,
+                       double *clock_mhz) {
     LSX_ARG(h && tflops && iters > 0 && blocks_per_cu >= 1 && blocks_per_cu <= 8);
-    return diag_mfma_peak(h, is_f32, iters, blocks_per_cu, tflops);
+    return diag_mfma_peak(h, is_f32, iters, blocks_per_cu, tflops, clock_mhz);
 }
 
 // ---- measurement

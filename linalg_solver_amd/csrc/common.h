@@ -66,6 +66,7 @@ struct lsx_handle_s {
     int lookahead = 0;   // 1: factor panel k+1 on side_stream under the trailing update of step k
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 256;   // threads per workgroup in the cooperative panel
+    int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     int num_cu = 256;
     // persistent device workspace (grown on demand, never shrunk)
@@ -148,7 +149,7 @@ template <typename T>
 int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out);
 template <typename T>
 int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out);
-int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops);
+int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz);
 template <typename T>
 int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd);
 

@@ -2,6 +2,8 @@
 // one workgroup of 4 waves per CU slot, 4 independent accumulators per wave; the
 // measured rate is what the trailing-update kernel is priced against next to
 // the datasheet peak (bench.py / DESIGN.md).
+#include <algorithm>
+
 #include "common.h"
 
 namespace lsx {
@@ -9,34 +11,62 @@ namespace lsx {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void mfma_peak_f64_kernel(int iters, double *out) {
+// stamps[block] = {shader-clock ticks, 100 MHz wall ticks} around the loop (wave 0 only): the
+// in-kernel clock is ticks_shader / ticks_wall * 100 MHz (MICROARCH guide, DVFS give-back item 6).
+__global__ __launch_bounds__(256) void mfma_peak_f64_kernel(int iters, double *out,
+                                                            unsigned long long *stamps) {
     d4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     double a = 1.0 + threadIdx.x * 1e-6, b = 1.0 - threadIdx.x * 1e-6;
-    for (int i = 0; i < iters; ++i) {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    // inline asm keeps the four accumulators in place: with the builtin hipcc copied all 32
+    // registers VGPR<->AGPR around every 4 MFMAs and the loop measured the copies, not the pipe
+    for (int i = 0; i < iters; i += 8) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[k], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n\t"
+                         "v_mfma_f64_16x16x4_f64 %1, %4, %5, %1\n\t"
+                         "v_mfma_f64_16x16x4_f64 %2, %4, %5, %2\n\t"
+                         "v_mfma_f64_16x16x4_f64 %3, %4, %5, %3"
+                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                         : "v"(a), "v"(b));
+        }
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     double s = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = c1 - c0;
+        stamps[2 * blockIdx.x + 1] = w1 - w0;
+    }
     if (s == 12345.678) out[0] = s;  // keep the chain alive without a store in practice
 }
 
 __global__ __launch_bounds__(256) void mfma_peak_f32_kernel(int iters, double *out) {
     f4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     float a = 1.0f + threadIdx.x * 1e-6f, b = 1.0f - threadIdx.x * 1e-6f;
-    for (int i = 0; i < iters; ++i) {
+    for (int i = 0; i < iters; i += 8) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[k], 0, 0, 0);
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("v_mfma_f32_16x16x4_f32 %0, %4, %5, %0\n\t"
+                         "v_mfma_f32_16x16x4_f32 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_16x16x4_f32 %2, %4, %5, %2\n\t"
+                         "v_mfma_f32_16x16x4_f32 %3, %4, %5, %3"
+                         : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                         : "v"(a), "v"(b));
+        }
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float s = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) s += acc[k][0] + acc[k][1] + acc[k][2] + acc[k][3];
     if (s == 12345.678f) out[0] = s;
 }
 
-int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops) {
+int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz) {
     const int grid = h->num_cu * blocks_per_cu;
+    unsigned long long *stamps = (unsigned long long *)((char *)h->scratch + 4096);
     hipEvent_t e0, e1;
     LSX_HIP(hipEventCreate(&e0));
     LSX_HIP(hipEventCreate(&e1));
@@ -46,7 +76,7 @@ int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, dou
         if (is_f32)
             hipLaunchKernelGGL(mfma_peak_f32_kernel, dim3(grid), dim3(256), 0, h->stream, iters, out);
         else
-            hipLaunchKernelGGL(mfma_peak_f64_kernel, dim3(grid), dim3(256), 0, h->stream, iters, out);
+            hipLaunchKernelGGL(mfma_peak_f64_kernel, dim3(grid), dim3(256), 0, h->stream, iters, out, is_f32 ? nullptr : stamps);
         LSX_HIP(hipEventRecord(e1, h->stream));
         LSX_HIP(hipEventSynchronize(e1));
     }
@@ -57,6 +87,20 @@ int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, dou
     // per MFMA 16x16x4: 2*16*16*4 flops; per wave iters*4 MFMAs; 4 waves per block
     const double flops = 2.0 * 16 * 16 * 4 * 4.0 * iters * 4.0 * grid;
     *tflops = flops / (ms * 1e-3) / 1e12;
+    if (clock_mhz) {
+        *clock_mhz = 0;
+        if (!is_f32) {
+            std::vector<unsigned long long> hs(2 * (size_t)grid);
+            LSX_HIP(hipMemcpy(hs.data(), stamps, hs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            std::vector<double> mhz;
+            for (int b = 0; b < grid; ++b)
+                if (hs[2 * b + 1] > 0) mhz.push_back((double)hs[2 * b] / (double)hs[2 * b + 1] * 100.0);
+            if (!mhz.empty()) {
+                std::sort(mhz.begin(), mhz.end());
+                *clock_mhz = mhz[mhz.size() / 2];
+            }
+        }
+    }
     return LSX_OK;
 }
 

@@ -53,13 +53,161 @@ struct Mfma<float> {
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) banks
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void gemm_sub_kernel(int M, int N, int K,
+// One 128 x 128 tile.  FULL = the tile lies inside the matrix, K is a multiple of BK and all
+// three operands are 16-byte aligned with even leading dimensions: every load/store is an
+// unpredicated 16-byte access.  Otherwise every element is bounds-checked (edge tiles, odd ld).
+// NWN = waves along N (2 or 4): the workgroup has 2*NWN waves, each owning a 64 x (128/NWN) piece.
+template <typename T, bool FULL, int NWN>
+__device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__restrict__ A, int lda,
+                                              const T *__restrict__ B, int ldb, T *__restrict__ C, int ldc,
+                                              int m0, int n0, T (*As)[BK][BM + LPAD], T (*Bs)[BK][BN + LPAD]) {
+    typedef typename Mfma<T>::acc_t acc_t;
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    constexpr int NT = 128 * NWN;      // threads
+    constexpr int WN = BN / NWN;       // wave tile width: 64 or 32
+    constexpr int TN = WN / 16;        // N-tiles per wave: 4 or 2
+    constexpr int NL = 1024 / NT;      // staging loads per thread and operand: 4 or 2
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = (wave / NWN) * 64, wn = (wave % NWN) * WN;
+    const int lc = lane & 15, lq = lane >> 4;
+
+    // ---- staging maps
+    // A slab 128 x 16: thread -> row (tid>>3) + (NT/8)*i, k-pair (tid&7)*2
+    // B slab 16 x 128: thread -> k (tid>>6) + (NT/64)*i, column pair (tid&63)*2
+    const int a_row = tid >> 3, a_k = (tid & 7) * 2;
+    const int b_k = tid >> 6, b_n = (tid & 63) * 2;
+    T ra[NL][2], rb[NL][2];
+
+    auto load_slab = [&](int k0) {
+        if (FULL) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const v2 v = *(const v2 *)(A + (size_t)(m0 + a_row + (NT / 8) * i) * lda + k0 + a_k);
+                ra[i][0] = v[0]; ra[i][1] = v[1];
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const v2 v = *(const v2 *)(B + (size_t)(k0 + b_k + (NT / 64) * i) * ldb + n0 + b_n);
+                rb[i][0] = v[0]; rb[i][1] = v[1];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int row = m0 + a_row + (NT / 8) * i;
+                const int kk = k0 + a_k;
+                const T *p = A + (size_t)row * lda + kk;
+                ra[i][0] = (row < M && kk < K) ? p[0] : T(0);
+                ra[i][1] = (row < M && kk + 1 < K) ? p[1] : T(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int kk = k0 + b_k + (NT / 64) * i;
+                const int col = n0 + b_n;
+                const T *p = B + (size_t)kk * ldb + col;
+                rb[i][0] = (kk < K && col < N) ? p[0] : T(0);
+                rb[i][1] = (kk < K && col + 1 < N) ? p[1] : T(0);
+            }
+        }
+    };
+    // column n of the tile -> wave piece h = n/WN, c = (n%WN)/TN, t = n%TN -> LDS column WN*h + 16*t + c
+    auto bperm = [](int n) { return (n / WN) * WN + 16 * (n % TN) + (n % WN) / TN; };
+    const int bp0 = bperm(b_n), bp1 = bperm(b_n + 1);
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            As[buf][a_k][a_row + (NT / 8) * i] = -ra[i][0];
+            As[buf][a_k + 1][a_row + (NT / 8) * i] = -ra[i][1];
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            Bs[buf][b_k + (NT / 64) * i][bp0] = rb[i][0];
+            Bs[buf][b_k + (NT / 64) * i][bp1] = rb[i][1];
+        }
+    };
+
+    // first slab goes out before the C loads so both latencies overlap
+    load_slab(0);
+
+    // ---- accumulators <- C.  Lane owns columns wn + TN*lc + t (t = N-tile index).
+    acc_t acc[4][TN];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
+            const int col = n0 + wn + TN * lc;
+            const T *p = C + (size_t)row * ldc + col;
+            T v[TN];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) v[t] = T(0);
+            if (FULL) {
+#pragma unroll
+                for (int t = 0; t < TN; t += 2) {
+                    const v2 x = *(const v2 *)(p + t);
+                    v[t] = x[0]; v[t + 1] = x[1];
+                }
+            } else if (row < M) {
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+                    if (col + t < N) v[t] = p[t];
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[s][t][r] = v[t];
+        }
+
+    const int nslab = (K + BK - 1) / BK;
+    store_slab(0);
+    __syncthreads();
+    for (int kt = 0; kt < nslab; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nslab) load_slab((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            T a[4], b[TN];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a[s] = As[buf][kk + lq][wm + 16 * s + lc];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b[t] = Bs[buf][kk + lq][wn + 16 * t + lc];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int t = 0; t < TN; ++t) acc[s][t] = Mfma<T>::mma(a[s], b[t], acc[s][t]);
+        }
+        if (kt + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- C <- accumulators
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
+            const int col = n0 + wn + TN * lc;
+            T *p = C + (size_t)row * ldc + col;
+            if (FULL) {
+#pragma unroll
+                for (int t = 0; t < TN; t += 2) {
+                    v2 x;
+                    x[0] = acc[s][t][r]; x[1] = acc[s][t + 1][r];
+                    *(v2 *)(p + t) = x;
+                }
+            } else if (row < M) {
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+                    if (col + t < N) p[t] = acc[s][t][r];
+            }
+        }
+}
+
+template <typename T, int NWN>
+__global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M, int N, int K,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
-                                                          int tiles_n) {
-    typedef typename Mfma<T>::acc_t acc_t;
+                                                          int tiles_n, int aligned) {
     __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
@@ -78,122 +226,11 @@ __global__ __launch_bounds__(256, 2) void gemm_sub_kernel(int M, int N, int K,
     const int tile_m = first_m + (bid % per_group) % gsize;
     const int tile_n = (bid % per_group) / gsize;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int lc = lane & 15, lq = lane >> 4;
-
-    // ---- accumulators <- C.  Lane owns columns wn + 4*lc + t (t = N-tile index).
-    acc_t acc[4][4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
-            const int col = n0 + wn + 4 * lc;
-            const T *p = C + (size_t)row * ldc + col;
-            T v[4] = {0, 0, 0, 0};
-            if (row < M) {
-                if (col + 3 < N) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = p[t];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (col + t < N) v[t] = p[t];
-                }
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[s][t][r] = v[t];
-        }
-
-    // ---- staging maps
-    // A slab 128 x 16: thread -> row (tid>>3) + 32*i, k-pair (tid&7)*2
-    // B slab 16 x 128: thread -> k (tid>>6) + 4*i, column pair (tid&63)*2
-    const int a_row = tid >> 3, a_k = (tid & 7) * 2;
-    const int b_k = tid >> 6, b_n = (tid & 63) * 2;
-    T ra[4][2], rb[4][2];
-
-    auto load_slab = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + a_row + 32 * i;
-            const int kk = k0 + a_k;
-            const T *p = A + (size_t)row * lda + kk;
-            ra[i][0] = (row < M && kk < K) ? p[0] : T(0);
-            ra[i][1] = (row < M && kk + 1 < K) ? p[1] : T(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kk = k0 + b_k + 4 * i;
-            const int col = n0 + b_n;
-            const T *p = B + (size_t)kk * ldb + col;
-            rb[i][0] = (kk < K && col < N) ? p[0] : T(0);
-            rb[i][1] = (kk < K && col + 1 < N) ? p[1] : T(0);
-        }
-    };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            As[buf][a_k][a_row + 32 * i] = -ra[i][0];
-            As[buf][a_k + 1][a_row + 32 * i] = -ra[i][1];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // column n (within the tile) -> wave half h = n>>6, c = (n&63)>>2, t = n&3 -> 64*h + 16*t + c
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int n = b_n + e;
-                const int np = (n & 64) + 16 * (n & 3) + ((n & 63) >> 2);
-                Bs[buf][b_k + 4 * i][np] = rb[i][e];
-            }
-        }
-    };
-
-    const int nslab = (K + BK - 1) / BK;
-    load_slab(0);
-    store_slab(0);
-    __syncthreads();
-    for (int kt = 0; kt < nslab; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nslab) load_slab((kt + 1) * BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            T a[4], b[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = As[buf][kk + lq][wm + 16 * s + lc];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) b[t] = Bs[buf][kk + lq][wn + 16 * t + lc];
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[s][t] = Mfma<T>::mma(a[s], b[t], acc[s][t]);
-        }
-        if (kt + 1 < nslab) store_slab(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- C <- accumulators
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
-            const int col = n0 + wn + 4 * lc;
-            T *p = C + (size_t)row * ldc + col;
-            if (row < M) {
-                if (col + 3 < N) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) p[t] = acc[s][t][r];
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (col + t < N) p[t] = acc[s][t][r];
-                }
-            }
-        }
+    const bool full = aligned && (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0);
+    if (full)
+        gemm_sub_tile<T, true, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    else
+        gemm_sub_tile<T, false, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
 }
 
 // Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
@@ -237,8 +274,17 @@ int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, co
                            n, k, A, lda, B, ldb, C, ldc);
     } else {
         const int tm = (m + BM - 1) / BM, tn = (n + BN - 1) / BN;
-        hipLaunchKernelGGL(gemm_sub_kernel<T>, dim3(tm * tn), dim3(256), 0, h->stream, m, n, k, A,
-                           lda, B, ldb, C, ldc, tm, tn);
+        const int elems16 = 16 / (int)sizeof(T);
+        const int aligned = ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) &&
+                            (lda % elems16 == 0) && (ldb % elems16 == 0) && (ldc % elems16 == 0);
+        // fp64: 8 waves (64x32 per wave, 4 waves/SIMD hide the C read); fp32: 4 waves measured faster
+        const int waves = h->gemm_waves ? h->gemm_waves : (sizeof(T) == 8 ? 8 : 4);
+        if (waves == 8)
+            hipLaunchKernelGGL((gemm_sub_kernel<T, 4>), dim3(tm * tn), dim3(512), 0, h->stream, m, n, k, A,
+                               lda, B, ldb, C, ldc, tm, tn, aligned);
+        else
+            hipLaunchKernelGGL((gemm_sub_kernel<T, 2>), dim3(tm * tn), dim3(256), 0, h->stream, m, n, k, A,
+                               lda, B, ldb, C, ldc, tm, tn, aligned);
     }
     LSX_HIP(hipGetLastError());
     return LSX_OK;

@@ -39,18 +39,23 @@ def main():
     dev = DeviceSolver()
     if "mfma" in args.what:
         for bpc in (1, 2):
-            print(f"mfma f64 peak ({bpc} WG/CU): {dev.h.mfma_peak(False, 20000, bpc):.1f} TFLOP/s   "
-                  f"f32: {dev.h.mfma_peak(True, 20000, bpc):.1f} TFLOP/s", flush=True)
+            t64, mhz = dev.h.mfma_peak(False, 200000, bpc)
+            t32, _ = dev.h.mfma_peak(True, 200000, bpc)
+            cyc = 2048.0 * 4 * 256 * bpc * 0 + (mhz * 1e6) / (t64 * 1e12 / (2048.0 * 1024 * (bpc if bpc < 2 else 1) )) if mhz else 0
+            print(f"mfma f64 ({bpc} WG/CU = {bpc} wave/SIMD): {t64:.1f} TFLOP/s at {mhz:.0f} MHz in-kernel clock "
+                  f"-> {t64 * 1e12 / 1024 / (mhz * 1e6) if mhz else 0:.1f} flop/clk/SIMD "
+                  f"(v_mfma_f64_16x16x4 = 2048 flop);   f32: {t32:.1f} TFLOP/s", flush=True)
     if "gemm" in args.what:
-        for dt in (torch.float64, torch.float32):
-            for m, k in ((8064, 128), (4096, 128), (2048, 128), (1024, 128), (8064, 256), (4096, 256), (8064, 64)):
+        for dt, gw in ((torch.float64, 4), (torch.float64, 8), (torch.float32, 4), (torch.float32, 8)):
+            dev.h.set_option("gemm_waves", gw)
+            for m, k in ((8064, 128), (4096, 128), (2048, 128), (8064, 256), (4096, 256)):
                 A = torch.randn(m, k, dtype=dt, device="cuda")
                 B = torch.randn(k, m, dtype=dt, device="cuda")
                 Cm = torch.randn(m, m, dtype=dt, device="cuda")
                 tmin, tmed = timeit(lambda: dev.gemm_sub_(Cm, A, B))
                 fl = 2.0 * m * m * k
                 by = 2.0 * Cm.element_size() * m * m
-                print(f"gemm_sub {str(dt)[6:]} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
+                print(f"gemm_sub {str(dt)[6:]} waves={gw} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
                       f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
     if "panel" in args.what:
         for mode, nt, rt in ((1, 256, 4), (1, 512, 4), (1, 512, 2), (1, 1024, 2), (1, 512, 8)):
@@ -72,6 +77,19 @@ def main():
                 t = tmin - tcopy
                 print(f"panel mode={mode} nt={nt} rt={rt} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)  "
                       f"{2 * 8 * m * args.nb / t / 1e6:.1f} GB/s", flush=True)
+    if "pmc" in args.what:
+        # workload for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`: two kernels of known byte counts
+        # (calibration) followed by the trailing-update kernel at LU-like shapes
+        m = 8064
+        Cm = torch.empty(m, m, dtype=torch.float64, device="cuda")
+        dev.fill_(Cm, gen.U11, 1)                   # lsx fill_kernel: writes m*m*8 B (8 B per lane)
+        Cc = Cm.clone()                             # torch copy: reads m*m*8 B, writes m*m*8 B
+        for k in (128, 256):
+            A = torch.randn(m, k, dtype=torch.float64, device="cuda")
+            B = torch.randn(k, m, dtype=torch.float64, device="cuda")
+            dev.gemm_sub_(Cm, A, B)                 # algorithmic: read + write C = 2*m*m*8 B (+ A, B slabs)
+        torch.cuda.synchronize()
+        print(f"pmc workload done: m={m}, C bytes one way = {m * m * 8}")
     if "stamps" in args.what:
         import numpy as np
         names = ["1:col update+cand", "barrier A", "2:reduce+publish", "3:bulk update", "4a:poll headers",
@@ -106,8 +124,8 @@ def main():
         ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         dev.h.set_option("panel_nt", 256)
-        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 2), (1, 4, 0, 128, 1), (1, 4, 1, 128, 1), (1, 4, 0, 64, 2),
-                                       (0, 4, 0, 128, 2)):
+        dev.h.set_option("gemm_waves", 0)
+        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 1), (1, 4, 0, 128, 2), (1, 4, 1, 128, 1)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
