@@ -128,29 +128,43 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 
 // Gather-list form: the cooperative panel kernel already knows every row's final position,
 // so the column chunks only have to move data (no per-workgroup replay of the interchanges).
+// Register-staged: a thread first issues ALL its loads (up to 32 independent 8-byte loads in
+// flight), then stores; a workgroup owns a 32-column chunk for every move, so all reads of the
+// chunk precede all writes without any LDS staging.  Each row segment is a 256-byte run.
 template <typename T, int CW>
 __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
                                                           const int2 *__restrict__ moves) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int *s_dst = (int *)smem;          // 256
-    int *s_src = s_dst + 256;          // 256
-    T *tile = (T *)(smem + 512 * sizeof(int));  // [256][CW]
+    __shared__ int s_dst[256], s_src[256];
+    __shared__ int s_n;
     const int tid = threadIdx.x;
-    {
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    {   // compact the valid moves (order is irrelevant: destinations are distinct)
         const int2 mv = moves[tid];
-        s_dst[tid] = mv.x;
-        s_src[tid] = mv.y;
+        if (mv.x >= 0) {
+            const int slot = atomicAdd(&s_n, 1);
+            s_dst[slot] = mv.x;
+            s_src[slot] = mv.y;
+        }
     }
     __syncthreads();
+    const int nmv = s_n;
     const int c0 = blockIdx.x * CW;
     const int tc = tid % CW, tr = tid / CW;
-    constexpr int RP = 256 / CW;
-    const bool cok = c0 + tc < ncols;
-    for (int d = tr; d < 256; d += RP)
-        if (s_dst[d] >= 0 && cok) tile[d * CW + tc] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
-    __syncthreads();
-    for (int d = tr; d < 256; d += RP)
-        if (s_dst[d] >= 0 && cok) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = tile[d * CW + tc];
+    constexpr int RP = 256 / CW;        // rows per pass
+    constexpr int NP = 256 / RP;        // passes (max moves / RP)
+    if (c0 + tc >= ncols) return;       // no barrier below this point
+    T v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int d = tr + RP * i;
+        if (d < nmv) v[i] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int d = tr + RP * i;
+        if (d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = v[i];
+    }
 }
 
 template <typename T>
@@ -158,11 +172,7 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
     if (ncols <= 0) return LSX_OK;
     constexpr int CW = 32;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
-    const size_t shm = 512 * sizeof(int) + (size_t)256 * CW * sizeof(T);
-    if (shm > 48 * 1024)
-        LSX_HIP(hipFuncSetAttribute((const void *)laswp_moves_kernel<T, CW>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
-    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), shm, h->stream,
+    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
                        ncols, A, lda, row0, (const int2 *)h->moves);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
@@ -346,6 +356,82 @@ __global__ __launch_bounds__(256) void trsm_block_kernel(int lower, int jb, int 
     }
 }
 
+// Fast path of the block solve for jb <= 128 (two 64-row blocks): the three 64 x 64 blocks it needs
+// (inv(T00), T10 or T01, inv(T11)) are fetched up front with all loads in flight at once, products
+// stay in MFMA accumulators (no temporary tile), and B makes one trip through LDS.
+template <typename T>
+__device__ __forceinline__ void lds_gemm_regs(const T *A, int lda, const T *B, int ldb, typename MfmaS<T>::acc_t (&acc)[2],
+                                              int wave, int lane) {
+    // D (64 x 32) = A (64 x 64) * B (64 x 32): 4 x 2 tiles, wave w owns tile row w (2 tiles)
+    const int lc = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        typename MfmaS<T>::acc_t a = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < 64; k0 += 4)
+            a = MfmaS<T>::mma(A[(16 * wave + lc) * lda + k0 + lq], B[(k0 + lq) * ldb + 16 * t + lc], a);
+        acc[t] = a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trsm_block2_kernel(int lower, int jb, int ncols,
+                                                          const T *__restrict__ Tm, int ldt,
+                                                          const T *__restrict__ Tinv, T *__restrict__ B,
+                                                          int ldb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BLD = CWT + 2;
+    T *Bs = (T *)smem;              // [128][BLD]
+    T *T0 = Bs + 128 * BLD;         // inverse of the first diagonal block to be applied
+    T *T1 = T0 + TB * TLD;          // off-diagonal block
+    T *T2 = T1 + TB * TLD;          // inverse of the second diagonal block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * CWT;
+    // order of the two 64-row blocks: lower = (0 then 1), upper = (1 then 0)
+    const int b_first = lower ? 0 : 1, b_second = lower ? 1 : 0;
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int i = e / TB, j = e % TB;
+        T0[i * TLD + j] = Tinv[(size_t)b_first * TB * TB + e];
+        T2[i * TLD + j] = Tinv[(size_t)b_second * TB * TB + e];
+        const int gi = b_second * TB + i, gj = b_first * TB + j;
+        T1[i * TLD + j] = (gi < jb && gj < jb) ? Tm[(size_t)gi * ldt + gj] : T(0);
+    }
+    for (int e = tid; e < 128 * CWT; e += 256) {
+        const int i = e / CWT, j = e % CWT;
+        Bs[i * BLD + j] = (i < jb && c0 + j < ncols) ? B[(size_t)i * ldb + c0 + j] : T(0);
+    }
+    __syncthreads();
+    typename MfmaS<T>::acc_t acc[2];
+    const int lc = lane & 15;
+    T *B1 = Bs + (size_t)b_first * TB * BLD, *B2 = Bs + (size_t)b_second * TB * BLD;
+    // X1 = inv(T11') * B1
+    lds_gemm_regs<T>(T0, TLD, B1, BLD, acc, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B1[(16 * wave + MfmaS<T>::crow(lane, r)) * BLD + 16 * t + lc] = acc[t][r];
+    __syncthreads();
+    // B2 -= T21 * X1
+    lds_gemm_regs<T>(T1, TLD, B1, BLD, acc, wave, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B2[(16 * wave + MfmaS<T>::crow(lane, r)) * BLD + 16 * t + lc] -= acc[t][r];
+    __syncthreads();
+    // X2 = inv(T22') * B2
+    lds_gemm_regs<T>(T2, TLD, B2, BLD, acc, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B2[(16 * wave + MfmaS<T>::crow(lane, r)) * BLD + 16 * t + lc] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < 128 * CWT; e += 256) {
+        const int i = e / CWT, j = e % CWT;
+        if (i < jb && c0 + j < ncols) B[(size_t)i * ldb + c0 + j] = Bs[i * BLD + j];
+    }
+}
+
 template <typename T>
 int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm, int ldt,
                       const T *Tinv, T *B, int ldb) {
@@ -357,6 +443,15 @@ int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm,
         return LSX_ERR_ARG;
     }
     ProfScope ps(h, LSX_PROF_TRSM, (double)jb * jb * ncols);
+    if (jb > 64 && jb <= 128) {
+        const size_t shm2 = ((size_t)128 * (CWT + 2) + 3 * TB * TLD) * sizeof(T);
+        LSX_HIP(hipFuncSetAttribute((const void *)trsm_block2_kernel<T>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2));
+        hipLaunchKernelGGL(trsm_block2_kernel<T>, dim3((ncols + CWT - 1) / CWT), dim3(256), shm2, h->stream,
+                           lower, jb, ncols, Tm, ldt, Tinv, B, ldb);
+        LSX_HIP(hipGetLastError());
+        return LSX_OK;
+    }
     if (shm > 48 * 1024)
         LSX_HIP(hipFuncSetAttribute((const void *)trsm_block_kernel<T>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));

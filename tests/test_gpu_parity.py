@@ -170,6 +170,13 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
         h.set_option("lookahead", 0)
         h.set_option("kblock", 1)
     assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])
+    # the blocked panel (mode 2) performs the same fused multiply-adds in the same order
+    try:
+        h.set_option("panel", 2)
+        LUb, ipivb, infob = dense.lu_factor(A)
+    finally:
+        h.set_option("panel", 1)
+    assert infob == 0 and np.array_equal(ipivb, results[3][1]) and np.array_equal(LUb, results[3][0])
     # tile height and look-ahead do not change a single bit
     assert np.array_equal(results[1][1], results[0][1]) and np.array_equal(results[1][0], results[0][0])
     assert np.array_equal(results[2][1], results[3][1]) and np.array_equal(results[2][0], results[3][0])
@@ -183,12 +190,13 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     assert relerr(LU, oLU) < TOL64
 
 
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("n", [16, 200, 513])
-def test_getrf_cooperative_panel_integer_and_singular(la, n):
+def test_getrf_cooperative_panel_integer_and_singular(la, n, mode):
     from linalg_solver_amd import dense, gen
 
     h = la.default_handle()
-    h.set_option("panel", 1)
+    h.set_option("panel", mode)
     try:
         A, _ = gen.system(gen.INT5, 60 + n, n)
         LU, ipiv, info = dense.lu_factor(A)

@@ -58,7 +58,7 @@ def main():
                 print(f"gemm_sub {str(dt)[6:]} waves={gw} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
                       f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
     if "panel" in args.what:
-        for mode, nt, rt in ((1, 256, 4), (1, 512, 4), (1, 512, 2), (1, 1024, 2), (1, 512, 8)):
+        for mode, nt, rt in ((2, 512, 4), (1, 256, 4)):
             dev.h.set_option("panel", mode)
             dev.h.set_option("panel_rt", rt)
             dev.h.set_option("panel_nt", nt)
@@ -125,7 +125,7 @@ def main():
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         dev.h.set_option("panel_nt", 256)
         dev.h.set_option("gemm_waves", 0)
-        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 1), (1, 4, 0, 128, 2), (1, 4, 1, 128, 1)):
+        for mode, rt, look, nb, kb in ((2, 4, 0, 128, 1), (1, 4, 0, 128, 1), (2, 4, 1, 128, 1), (2, 4, 0, 128, 2)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
