@@ -163,8 +163,9 @@ int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, floa
                      int row_off, int col_off);
 
 /* ---- measurement --------------------------------------------------------- */
-/* When enabled, every kernel launch of the buckets above is bracketed by HIP
- * events on the launch stream; lsx_prof_read sums them (synchronises). */
+/* When enabled, every kernel launch of the selected buckets is bracketed by HIP
+ * events on the launch stream; lsx_prof_read sums them (synchronises).
+ * on: 0 = off, 1 = all buckets, otherwise (bucket mask << 1), e.g. 2 << LSX_PROF_GEMM. */
 int lsx_prof_enable(lsx_handle_t h, int on);
 int lsx_prof_reset(lsx_handle_t h);
 int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, double *flops,

@@ -175,8 +175,15 @@ class Handle:
         return buf.raw
 
     # measurement
-    def prof_enable(self, on: bool = True):
-        check(self.lib.lsx_prof_enable(self._h, 1 if on else 0))
+    def prof_enable(self, on=True, buckets=None):
+        """on=True: every bucket; buckets=("gemm",): only those; on=False: off."""
+        if buckets:
+            arg = 0
+            for b in buckets:
+                arg |= 2 << PROF_BUCKETS[b]
+        else:
+            arg = 1 if on else 0
+        check(self.lib.lsx_prof_enable(self._h, arg))
 
     def prof_reset(self):
         check(self.lib.lsx_prof_reset(self._h))

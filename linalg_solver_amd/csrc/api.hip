@@ -46,7 +46,7 @@ static int ensure_scratch(lsx_handle_t h, size_t bytes) {
 
 ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : h(h_), st(h_->stream) {
     Prof &p = h->prof;
-    if (!p.on) return;
+    if (!((p.mask >> bucket) & 1u)) return;
     ProfEvent ev;
     ev.bucket = bucket;
     for (hipEvent_t *e : {&ev.a, &ev.b}) {
@@ -700,7 +700,9 @@ int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu,
 // ---- measurement
 int lsx_prof_enable(lsx_handle_t h, int on) {
     LSX_ARG(h);
-    h->prof.on = on != 0;
+    // 0 = off, 1 = every bucket, otherwise a bit mask (1 << LSX_PROF_*) shifted left by one:
+    // e.g. 2 << LSX_PROF_GEMM brackets only the trailing-update launches
+    h->prof.mask = on == 1 ? 0xffffffffu : (unsigned)on >> 1;
     return LSX_OK;
 }
 

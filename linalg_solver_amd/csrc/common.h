@@ -42,7 +42,7 @@ struct ProfEvent {
 };
 
 struct Prof {
-    bool on = false;
+    unsigned mask = 0;  // bit b set: launches of bucket b are bracketed by events
     std::vector<ProfEvent> pending;
     std::vector<hipEvent_t> pool;
     double ms[LSX_PROF_NBUCKETS] = {0};

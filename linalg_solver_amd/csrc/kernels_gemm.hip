@@ -179,13 +179,17 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
         __syncthreads();
     }
 
-    // ---- C <- accumulators
+    // ---- C <- accumulators.  The lane id is laundered so the row addresses are recomputed here
+    // instead of being kept alive (and spilled to scratch) across the whole k-loop.
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lc_e = lane_e & 15;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
-            const int col = n0 + wn + TN * lc;
+            const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane_e, r);
+            const int col = n0 + wn + TN * lc_e;
             T *p = C + (size_t)row * ldc + col;
             if (FULL) {
 #pragma unroll
@@ -202,12 +206,16 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
         }
 }
 
-template <typename T, int NWN>
+// FULL = true: interior tiles only (grid covers tiles_m x tiles_n complete tiles, operands aligned);
+// FULL = false: any tile, every access bounds-checked.  Two kernels rather than one branch so the
+// interior kernel's register allocation is not set by the edge path (it spilled inside 128 VGPRs).
+// (tm_off, tn_off) shift the tile grid so edge strips can be covered by separate launches.
+template <typename T, int NWN, bool FULL>
 __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M, int N, int K,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
-                                                          int tiles_n, int aligned) {
+                                                          int tiles_n, int tm_off, int tn_off) {
     __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
@@ -225,12 +233,8 @@ __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M,
     const int gsize = min(tiles_m - first_m, GROUP);
     const int tile_m = first_m + (bid % per_group) % gsize;
     const int tile_n = (bid % per_group) / gsize;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const bool full = aligned && (m0 + BM <= M) && (n0 + BN <= N) && (K % BK == 0);
-    if (full)
-        gemm_sub_tile<T, true, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
-    else
-        gemm_sub_tile<T, false, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    const int m0 = (tile_m + tm_off) * BM, n0 = (tile_n + tn_off) * BN;
+    gemm_sub_tile<T, FULL, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
 }
 
 // Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
@@ -275,16 +279,25 @@ int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, co
     } else {
         const int tm = (m + BM - 1) / BM, tn = (n + BN - 1) / BN;
         const int elems16 = 16 / (int)sizeof(T);
-        const int aligned = ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) &&
-                            (lda % elems16 == 0) && (ldb % elems16 == 0) && (ldc % elems16 == 0);
+        const bool aligned = ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) &&
+                             (lda % elems16 == 0) && (ldb % elems16 == 0) && (ldc % elems16 == 0) && (k % BK == 0);
         // fp64: 8 waves (64x32 per wave, 4 waves/SIMD hide the C read); fp32: 4 waves measured faster
         const int waves = h->gemm_waves ? h->gemm_waves : (sizeof(T) == 8 ? 8 : 4);
-        if (waves == 8)
-            hipLaunchKernelGGL((gemm_sub_kernel<T, 4>), dim3(tm * tn), dim3(512), 0, h->stream, m, n, k, A,
-                               lda, B, ldb, C, ldc, tm, tn, aligned);
-        else
-            hipLaunchKernelGGL((gemm_sub_kernel<T, 2>), dim3(tm * tn), dim3(256), 0, h->stream, m, n, k, A,
-                               lda, B, ldb, C, ldc, tm, tn, aligned);
+        const int fm = aligned ? m / BM : 0, fn = aligned ? n / BN : 0;  // complete tiles
+        auto go = [&](bool full, int gm, int gn, int om, int on) {
+            if (gm <= 0 || gn <= 0) return;
+            const dim3 grid(gm * gn);
+            if (waves == 8) {
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+            } else {
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+            }
+        };
+        go(true, fm, fn, 0, 0);                 // interior
+        go(false, tm - fm, tn, fm, 0);          // bottom strip (all columns)
+        go(false, fm, tn - fn, 0, fn);          // right strip (complete tile rows only)
     }
     LSX_HIP(hipGetLastError());
     return LSX_OK;

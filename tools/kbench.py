@@ -84,6 +84,7 @@ def main():
         Cm = torch.empty(m, m, dtype=torch.float64, device="cuda")
         dev.fill_(Cm, gen.U11, 1)                   # lsx fill_kernel: writes m*m*8 B (8 B per lane)
         Cc = Cm.clone()                             # torch copy: reads m*m*8 B, writes m*m*8 B
+        dev.h.set_option("gemm_waves", 0)
         for k in (128, 256):
             A = torch.randn(m, k, dtype=torch.float64, device="cuda")
             B = torch.randn(k, m, dtype=torch.float64, device="cuda")
