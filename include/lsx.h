@@ -122,7 +122,9 @@ int lsx_gesv_f32(lsx_handle_t h, int n, int nrhs, const float *A, int lda, float
                  int *info, double *pivot_ratio);
 
 /* ---- device-pointer entry points (asynchronous on the handle's stream) ---- */
-/* d_info: device int (may be NULL).  d_ipiv: device int32[n]. */
+/* d_info: device int (may be NULL).  d_ipiv: device int32[n].
+ * *d_info < 0 after the call means the in-kernel pivot exchange timed out (LSX_ERR_INTERNAL
+ * in the host-buffer forms): the factors are not valid. */
 int lsx_getrf_f64_dev(lsx_handle_t h, int n, double *dA, int lda, int32_t *d_ipiv, int *d_info);
 int lsx_getrs_f64_dev(lsx_handle_t h, int n, int nrhs, const double *dLU, int lda,
                       const int32_t *d_ipiv, double *dB, int ldb);

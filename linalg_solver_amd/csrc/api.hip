@@ -239,6 +239,16 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
     LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
     LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nrhs));
     LSX_TRY(launch_gather_rows<T>(h, n, nrhs, perm, Bc, nrhs, B, ldb));
+    if ((nrhs == 1 || nrhs == 2 || nrhs == 4 || nrhs == 8) && n > 128) {
+        // solve-latency path: one launch per 128-row block step (kernels_trsv.hip)
+        const size_t b64 = pad256((size_t)((n + 63) / 64) * 64 * 64 * sizeof(T));
+        const size_t b128 = pad256((size_t)((n + 127) / 128) * 128 * 128 * sizeof(T));
+        LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * b64 + 2 * b128));
+        char *w = (char *)h->ws2;
+        LSX_TRY(lu_solve_few_rhs<T>(h, n, nrhs, LU, lda, B, ldb, Bc, (T *)w, (T *)(w + b64), (T *)(w + 2 * b64),
+                                    (T *)(w + 2 * b64 + b128)));
+        return launch_copy2d<T>(h, n, nrhs, Bc, nrhs, B, ldb);
+    }
     return lu_solve_permuted<T>(h, n, nrhs, LU, lda, B, ldb);
 }
 
@@ -289,6 +299,10 @@ static int getrf_host(lsx_handle_t h, int n, T *A, int lda, int32_t *ipiv, int *
     LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
+    if (hinfo < 0) {
+        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
+        return LSX_ERR_INTERNAL;
+    }
     return LSX_OK;
 }
 
@@ -343,6 +357,10 @@ static int gesv_host(lsx_handle_t h, int n, int nrhs, const T *A, int lda, T *B,
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
     if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
+    if (hinfo < 0) {
+        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
+        return LSX_ERR_INTERNAL;
+    }
     if (hinfo != 0 || nrhs == 0) return LSX_OK;  // singular: B is left untouched
     LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
     LSX_TRY(d2h<T>(h, n, nrhs, dB, ldx, B, ldb));
@@ -550,6 +568,10 @@ int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv,
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
     if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
+    if (hinfo < 0) {
+        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
+        return LSX_ERR_INTERNAL;
+    }
     if (hinfo != 0) return LSX_OK;  // exactly singular: caller reports NoSolution (linalg.py:737)
     LSX_TRY(getri_dev<double>(h, n, dA, ld, dp, dI, ld));
     LSX_TRY(d2h<double>(h, n, n, dI, ld, Ainv, ldi));

@@ -149,6 +149,10 @@ template <typename T>
 int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out);
 template <typename T>
 int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out);
+// X (n x nrhs, ld = nrhs) <- U^-1 L^-1 B, nrhs <= 8, one launch per 128-row block step
+template <typename T>
+int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B, int ldb, T *X, T *inv64L,
+                     T *inv64U, T *inv128L, T *inv128U);
 int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz);
 template <typename T>
 int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd);

@@ -129,8 +129,9 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // Gather-list form: the cooperative panel kernel already knows every row's final position,
 // so the column chunks only have to move data (no per-workgroup replay of the interchanges).
 // Register-staged: a thread first issues ALL its loads (up to 32 independent 8-byte loads in
-// flight), then stores; a workgroup owns a 32-column chunk for every move, so all reads of the
-// chunk precede all writes without any LDS staging.  Each row segment is a 256-byte run.
+// flight), the workgroup synchronises (a row can be source and destination of different moves),
+// then everything is stored; a workgroup owns a 32-column chunk for every move, so no other
+// workgroup touches these columns.  Each row segment is a 256-byte run.
 template <typename T, int CW>
 __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
                                                           const int2 *__restrict__ moves) {
@@ -153,17 +154,20 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
     const int tc = tid % CW, tr = tid / CW;
     constexpr int RP = 256 / CW;        // rows per pass
     constexpr int NP = 256 / RP;        // passes (max moves / RP)
-    if (c0 + tc >= ncols) return;       // no barrier below this point
+    const bool cok = c0 + tc < ncols;
     T v[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int d = tr + RP * i;
-        if (d < nmv) v[i] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
+        if (cok && d < nmv) v[i] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
     }
+    // a row may be the source of one move and the destination of another: every load of the
+    // chunk must have returned before any thread of the workgroup stores
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int d = tr + RP * i;
-        if (d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = v[i];
+        if (cok && d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = v[i];
     }
 }
 

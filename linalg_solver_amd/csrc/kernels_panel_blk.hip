@@ -399,6 +399,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
     }
     __syncthreads();
     if (tid == 0) replay(jb - 1);
+    // a workgroup whose exchange timed out reports it through info (negative = protocol failure):
+    // the host entry points turn that into LSX_ERR_INTERNAL instead of returning garbage factors
+    if (failed && info && (tid & 63) == 0) atomicMin(info, -0x40000000);
     __syncthreads();
     if (g == 0 && moves) {
         for (int t = tid; t < 2 * PB_COLS; t += NT) {

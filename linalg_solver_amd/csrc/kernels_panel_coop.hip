@@ -366,6 +366,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
     // the last column's deferred update touches only columns > jb-1: nothing left inside the panel
     __syncthreads();
     if (tid == 0) replay(jb - 1);
+    // a workgroup whose exchange timed out reports it through info (negative = protocol failure):
+    // the host entry points turn that into LSX_ERR_INTERNAL instead of returning garbage factors
+    if (failed && info && (tid & 63) == 0) atomicMin(info, -0x40000000);
     __syncthreads();
     // ---- the same permutation as a gather list for the columns outside the panel:
     // final[row0 + dst] = old[row0 + src]; slot j: pivot j, slot PC_COLS + d: displaced top row d
