@@ -490,7 +490,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
         LSX_ARG(value == 2 || value == 4 || value == 8);
         h->panel_rt = value;
     } else if (!strcmp(key, "panel_nt")) {
-        LSX_ARG(value == 256 || value == 512 || value == 1024);
+        LSX_ARG(value == 0 || value == 256 || value == 512 || value == 1024);
         h->panel_nt = value;
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;

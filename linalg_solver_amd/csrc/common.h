@@ -65,7 +65,7 @@ struct lsx_handle_s {
     int panel_mode = 1;  // 0 = per-column launches, 1 = cooperative kernel
     int lookahead = 0;   // 1: factor panel k+1 on side_stream under the trailing update of step k
     int panel_rt = 4;     // rows per thread in the cooperative panel
-    int panel_nt = 256;   // threads per workgroup in the cooperative panel
+    int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     int num_cu = 256;
@@ -107,6 +107,23 @@ template <>
 struct Real<float> {
     static constexpr float eps = 1.1920929e-07f;
 };
+
+// 1/x for the pivot scaling of every panel kernel (the same function everywhere so the three
+// panel modes stay bit-identical): hardware reciprocal + Newton, <= 1 ulp; an IEEE division
+// costs ~40 instructions on the per-column critical path.
+template <typename T>
+__device__ __forceinline__ T fast_recip(T x) {
+    if (sizeof(T) == 8) {
+        double r = __builtin_amdgcn_rcp((double)x);
+        r = r * (2.0 - (double)x * r);
+        r = r * (2.0 - (double)x * r);
+        return (T)r;
+    }
+    float r = __builtin_amdgcn_rcpf((float)x);
+    r = r * (2.0f - (float)x * r);
+    return (T)r;
+}
+
 
 // ---- kernel launchers (one per .hip file section); all asynchronous on h->stream ----
 template <typename T>

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void panel_update_kernel(int m, int jb, T *__r
     T piv = T(1), rinv = T(0);
     if (j >= 0) {
         piv = P[(size_t)j * ldp + j];
-        rinv = (piv != T(0)) ? T(1) / piv : T(0);
+        rinv = (piv != T(0)) ? fast_recip<T>(piv) : T(0);
     }
     T best = T(-1);
     int besti = 0x7fffffff;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
             }
         }
         if (tx == jt && act) {
-            const T rinv = T(1) / piv;
+            const T rinv = fast_recip<T>(piv);
             T u[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) u[c] = s_ub[c];

@@ -73,6 +73,38 @@ struct __attribute__((aligned(16))) XGran {
 // `switch` on the column made hipcc shuffle the tile through AGPRs: 1.3k v_accvgpr and
 // 370 branches, 5 us per column); conditionals on per-row state are selects, not
 // branches; the tile is RT x 8 with RT = 4 so the whole state stays in arch VGPRs.
+// ---- DPP cross-lane moves: VALU-rate, no trip through the LDS crossbar (ds_bpermute costs ~100+
+// cycles per dependent step).  Applied in the order quad xor 1, quad xor 2, row_half_mirror,
+// row_mirror they leave every lane of a 16-lane row with the row's reduction (max with ties).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+#define LSX_DPP_STEP(CTRL, v, i)                                         \
+    {                                                                    \
+        const double ov_ = dpp_d<CTRL>(v);                               \
+        const int oi_ = dpp_i<CTRL>(i);                                  \
+        const bool b_ = (ov_ > v) | ((ov_ == v) & (oi_ < i));            \
+        v = b_ ? ov_ : v;                                                \
+        i = b_ ? oi_ : i;                                                \
+    }
+// arg-max (largest v, lowest i on ties) over each 16-lane row
+__device__ __forceinline__ void row16_argmax(double &v, int &i) {
+    LSX_DPP_STEP(0xB1, v, i)   // quad_perm [1,0,3,2]
+    LSX_DPP_STEP(0x4E, v, i)   // quad_perm [2,3,0,1]
+    LSX_DPP_STEP(0x141, v, i)  // row_half_mirror
+    LSX_DPP_STEP(0x140, v, i)  // row_mirror
+}
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
 template <typename T, int RT, int NT, bool DBG>
 __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb, T *__restrict__ P, int ldp,
                                                             int row0, int col0,
@@ -185,13 +217,23 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
         constexpr int NCM = NTY < 64 ? NTY : 64;
         double wv = s_cv[lane & (NCM - 1)];
         int wi = s_ci[lane & (NCM - 1)];
+        row16_argmax(wv, wi);
+        if (NCM > 16) {  // thread rows beyond 16: combine the 16-lane rows through scalar registers
+            double rv[NCM / 16];
+            int ri[NCM / 16];
 #pragma unroll
-        for (int off = NCM / 2; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(wv, off, 64);
-            const int oi = __shfl_xor(wi, off, 64);
-            const bool better = (ov > wv) | ((ov == wv) & (oi < wi));
-            wv = better ? ov : wv;
-            wi = better ? oi : wi;
+            for (int rr = 0; rr < NCM / 16; ++rr) {
+                rv[rr] = readlane_d(wv, 16 * rr);
+                ri[rr] = __builtin_amdgcn_readlane(wi, 16 * rr);
+            }
+            wv = rv[0];
+            wi = ri[0];
+#pragma unroll
+            for (int rr = 1; rr < NCM / 16; ++rr) {
+                const bool better = (rv[rr] > wv) | ((rv[rr] == wv) & (ri[rr] < wi));
+                wv = better ? rv[rr] : wv;
+                wi = better ? ri[rr] : wi;
+            }
         }
         const bool have = wv >= 0.0;
         const int cl = have ? wi - base : 0;          // slice-local row of the candidate
@@ -281,15 +323,38 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            // 64-lane arg-max carrying the workgroup id: 16-lane rows by DPP, the 4 rows by readlane
+            {
+                // pack (row, workgroup) so one integer travels with the value; ties -> lowest row
+                long long key = ((long long)bi << 20) | (long long)bg;  // bg < 2^20
+                int klo = (int)(key & 0xffffffffll), khi = (int)(key >> 32);
+#define LSX_DPP_STEP3(CTRL)                                                                   \
+                {                                                                             \
+                    const double ov_ = dpp_d<CTRL>(bv);                                       \
+                    const int olo_ = dpp_i<CTRL>(klo), ohi_ = dpp_i<CTRL>(khi);               \
+                    const long long ok_ = ((long long)ohi_ << 32) | (unsigned)olo_;            \
+                    const long long mk_ = ((long long)khi << 32) | (unsigned)klo;              \
+                    const bool b_ = (ov_ > bv) | ((ov_ == bv) & (ok_ < mk_));                  \
+                    bv = b_ ? ov_ : bv;                                                       \
+                    klo = b_ ? olo_ : klo;                                                    \
+                    khi = b_ ? ohi_ : khi;                                                    \
+                }
+                LSX_DPP_STEP3(0xB1) LSX_DPP_STEP3(0x4E) LSX_DPP_STEP3(0x141) LSX_DPP_STEP3(0x140)
+#undef LSX_DPP_STEP3
+                double rv = readlane_d(bv, 0);
+                long long rk = ((long long)__builtin_amdgcn_readlane(khi, 0) << 32) | (unsigned)__builtin_amdgcn_readlane(klo, 0);
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const double ov = __shfl_xor(bv, off, 64);
-                const int oi = __shfl_xor(bi, off, 64);
-                const int og = __shfl_xor(bg, off, 64);
-                const bool better = (ov > bv) | ((ov == bv) & (oi < bi));
-                bv = better ? ov : bv;
-                bi = better ? oi : bi;
-                bg = better ? og : bg;
+                for (int rr = 1; rr < 4; ++rr) {
+                    const double ov = readlane_d(bv, 16 * rr);
+                    const long long ok = ((long long)__builtin_amdgcn_readlane(khi, 16 * rr) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane(klo, 16 * rr);
+                    const bool b = (ov > rv) | ((ov == rv) & (ok < rk));
+                    rv = b ? ov : rv;
+                    rk = b ? ok : rk;
+                }
+                bv = rv;
+                bi = (int)(rk >> 20);
+                bg = (int)(rk & 0xfffff);
             }
             const bool valid = bv >= 0.0;
             STAMP(4)
@@ -336,7 +401,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
             }
         }
         const bool act = valid & (piv != T(0));
-        const T rinv = act ? T(1) / piv : T(0);
+        const T rinv = act ? fast_recip<T>(piv) : T(0);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
             const T v = s_col[par][NTY * r + ty] * rinv;
@@ -444,6 +509,10 @@ int panel_cooperative(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, in
     // number of workgroups that take part in every exchange; all of them must be resident at once.
     int nt = h->panel_nt, rt = h->panel_rt;
     auto rows = [](int nt_, int rt_) { return nt_ / 16 * rt_; };
+    if (h->panel_nt == 0) {  // auto: tall panels poll faster with half as many workgroups
+        nt = m >= 6144 ? 512 : 256;
+        rt = 4;
+    }
     if ((m + rows(nt, rt) - 1) / rows(nt, rt) > h->num_cu) { nt = 512; rt = 8; }  // 256-row slices
     const int G = (m + rows(nt, rt) - 1) / rows(nt, rt);
     if (G > h->num_cu) return 1;

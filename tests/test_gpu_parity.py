@@ -166,7 +166,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
             results.append(dense.lu_factor(A))
     finally:
         h.set_option("panel_rt", 4)
-        h.set_option("panel_nt", 256)
+        h.set_option("panel_nt", 0)
         h.set_option("lookahead", 0)
         h.set_option("kblock", 1)
     assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])

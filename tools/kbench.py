@@ -58,7 +58,7 @@ def main():
                 print(f"gemm_sub {str(dt)[6:]} waves={gw} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
                       f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
     if "panel" in args.what:
-        for mode, nt, rt in ((2, 512, 4), (1, 256, 4)):
+        for mode, nt, rt in ((1, 256, 4), (1, 512, 4)):
             dev.h.set_option("panel", mode)
             dev.h.set_option("panel_rt", rt)
             dev.h.set_option("panel_nt", nt)
@@ -97,8 +97,7 @@ def main():
                  "4b:row granules", "barrier C", "5:multipliers"]
         dev.h.set_option("panel", 1)
         dev.h.set_option("panel_debug", 1)
-        for nt, rt, m in ((256, 4, args.n), (512, 4, args.n), (512, 2, args.n), (1024, 2, args.n), (512, 8, args.n),
-                          (512, 4, 1024), (1024, 2, 1024)):
+        for nt, rt, m in ((256, 4, args.n), (512, 4, args.n), (256, 4, 1024), (256, 4, 128)):
             dev.h.set_option("panel_rt", rt)
             dev.h.set_option("panel_nt", nt)
             P = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
@@ -124,9 +123,9 @@ def main():
         A = A0.clone()
         ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
-        dev.h.set_option("panel_nt", 256)
+        dev.h.set_option("panel_nt", 0)
         dev.h.set_option("gemm_waves", 0)
-        for mode, rt, look, nb, kb in ((2, 4, 0, 128, 1), (1, 4, 0, 128, 1), (2, 4, 1, 128, 1), (2, 4, 0, 128, 2)):
+        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 1), (2, 4, 0, 128, 1)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
