@@ -102,15 +102,63 @@ static int apply_panel_swaps(lsx_handle_t h, int ncols, T *Acols, int lda, int r
 //   side:                                   wait N(k) | panel(k+1) | record P(k+1)
 // Disjointness: panel(k+1) owns columns [k+jb, k+2jb) x rows >= k+jb; gemm(rest) writes
 // columns >= k+2jb and reads L21 (columns [k,k+jb)) and U12 (rows [k,k+jb)).
+// Two streams masked to disjoint CU sets: `panel_cus` CUs (every (256/panel_cus)-th one, so both
+// sets span all XCDs and memory channels) for the panel, the rest for the update.
+static int ensure_partition(lsx_handle_t h, int panel_cus) {
+    if (h->part_panel_cus == panel_cus && h->part_update && h->part_panel) return LSX_OK;
+    if (h->part_update) { (void)hipStreamDestroy(h->part_update); h->part_update = nullptr; }
+    if (h->part_panel) { (void)hipStreamDestroy(h->part_panel); h->part_panel = nullptr; }
+    h->part_panel_cus = 0;
+    const int ncu = h->num_cu;
+    std::vector<uint32_t> mp((ncu + 31) / 32, 0u), mu((ncu + 31) / 32, 0u);
+    const int stride = ncu / panel_cus;
+    int given = 0;
+    for (int cu = 0; cu < ncu; ++cu) {
+        const bool to_panel = (stride > 0) && (cu % stride == stride - 1) && given < panel_cus;
+        if (to_panel) { mp[cu / 32] |= 1u << (cu % 32); ++given; }
+        else mu[cu / 32] |= 1u << (cu % 32);
+    }
+    if (given < panel_cus) { set_error("CU partition: cannot give %d CUs to the panel", panel_cus); return LSX_ERR_ARG; }
+    LSX_HIP(hipExtStreamCreateWithCUMask(&h->part_update, (uint32_t)mu.size(), mu.data()));
+    LSX_HIP(hipExtStreamCreateWithCUMask(&h->part_panel, (uint32_t)mp.size(), mp.data()));
+    h->part_panel_cus = panel_cus;
+    return LSX_OK;
+}
+
 template <typename T>
 static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv) {
     const int nb = h->nb;
-    hipStream_t main_s = h->stream, side = h->side_stream;
-    struct OnSide {  // launches inside this scope go to the side stream
+    struct OnSide {  // launches inside this scope go to the given stream
         lsx_handle_t h; hipStream_t keep;
         OnSide(lsx_handle_t h_, hipStream_t s) : h(h_), keep(h_->stream) { h->stream = s; }
         ~OnSide() { h->stream = keep; }
     };
+    hipStream_t caller = h->stream;
+    hipStream_t main_s = h->stream, side = h->side_stream;
+    const bool partitioned = h->lookahead == 2;
+    if (partitioned) {
+        // the panel's workgroups (128 rows each in the tall-panel shape) all need a CU of their own
+        int want = (n + 127) / 128;
+        want = want < 16 ? 16 : want;
+        if (want * 2 > h->num_cu) want = h->num_cu / 2;
+        int pcus = 16;
+        while (pcus < want) pcus *= 2;
+        LSX_TRY(ensure_partition(h, pcus));
+        main_s = h->part_update;
+        side = h->part_panel;
+    }
+    struct Restore {  // the handle's stream is the update stream while this driver runs
+        lsx_handle_t h; hipStream_t keep; int nt, rt;
+        ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; }
+    } restore{h, caller, h->panel_nt, h->panel_rt};
+    if (partitioned) {
+        // every panel workgroup must be resident inside the panel's CU set: 128-row slices only
+        h->panel_nt = 512;
+        h->panel_rt = 4;
+        LSX_HIP(hipEventRecord(h->ev_start, caller));
+        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_start, 0));
+        h->stream = main_s;
+    }
     // the side stream starts after everything already queued on the main stream (info memset, fills)
     LSX_HIP(hipEventRecord(h->ev_start, main_s));
     LSX_HIP(hipStreamWaitEvent(side, h->ev_start, 0));
@@ -144,6 +192,10 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         }
         if (rest > jb2)
             LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
+    }
+    if (partitioned) {  // hand the result back to the caller's stream
+        LSX_HIP(hipEventRecord(h->ev_done, main_s));
+        LSX_HIP(hipStreamWaitEvent(caller, h->ev_done, 0));
     }
     return LSX_OK;
 }
@@ -415,7 +467,8 @@ int lsx_create(lsx_handle_t *out, int device) {
         if (hipStreamCreateWithPriority(&h->side_stream, hipStreamNonBlocking, hi) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_panel, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_next, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
             set_error("could not create the look-ahead stream / events");
             (void)hipStreamDestroy(h->own_stream);
             delete h;
@@ -446,6 +499,9 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
+    if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+    if (h->part_update) (void)hipStreamDestroy(h->part_update);
+    if (h->part_panel) (void)hipStreamDestroy(h->part_panel);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -495,7 +551,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
-        LSX_ARG(value == 0 || value == 1);
+        LSX_ARG(value >= 0 && value <= 2);
         h->lookahead = value;
     } else {
         set_error("unknown option '%s'", key);

@@ -124,6 +124,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
     __shared__ int s_topid[PC_COLS], s_postop[PC_COLS];
     __shared__ int s_order[RB];
 
+    // latency-critical and tiny: when the look-ahead driver runs this kernel beside the trailing
+    // update, its waves must win issue arbitration against the co-resident MFMA waves
+    __builtin_amdgcn_s_setprio(3);
     const int G = gridDim.x, g = blockIdx.x;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;

@@ -157,7 +157,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     oLU, oipiv, oinfo = capi.getrf(A)
     results = []
     try:
-        for rt, look, kb, nt in ((4, 0, 2, 256), (8, 0, 2, 512), (4, 1, 1, 512), (4, 0, 1, 256), (2, 0, 1, 1024)):
+        for rt, look, kb, nt in ((4, 0, 2, 256), (8, 0, 2, 512), (4, 1, 1, 512), (4, 0, 1, 256), (2, 2, 1, 1024)):
             h.set_option("panel", 1)
             h.set_option("panel_rt", rt)
             h.set_option("panel_nt", nt)
