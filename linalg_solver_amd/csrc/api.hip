@@ -3,6 +3,7 @@
 // no host synchronisation inside a factorisation or solve: pivots, info and
 // rank stay on the device, so a whole getrf is graph-capturable.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -102,8 +103,7 @@ static int apply_panel_swaps(lsx_handle_t h, int ncols, T *Acols, int lda, int r
 //   side:                                   wait N(k) | panel(k+1) | record P(k+1)
 // Disjointness: panel(k+1) owns columns [k+jb, k+2jb) x rows >= k+jb; gemm(rest) writes
 // columns >= k+2jb and reads L21 (columns [k,k+jb)) and U12 (rows [k,k+jb)).
-// Two streams masked to disjoint CU sets: `panel_cus` CUs (every (256/panel_cus)-th one, so both
-// sets span all XCDs and memory channels) for the panel, the rest for the update.
+// Two streams masked to disjoint CU sets: `panel_cus` CUs for the panel, the rest for the update.
 static int ensure_partition(lsx_handle_t h, int panel_cus) {
     if (h->part_panel_cus == panel_cus && h->part_update && h->part_panel) return LSX_OK;
     if (h->part_update) { (void)hipStreamDestroy(h->part_update); h->part_update = nullptr; }
@@ -111,11 +111,11 @@ static int ensure_partition(lsx_handle_t h, int panel_cus) {
     h->part_panel_cus = 0;
     const int ncu = h->num_cu;
     std::vector<uint32_t> mp((ncu + 31) / 32, 0u), mu((ncu + 31) / 32, 0u);
-    const int stride = ncu / panel_cus;
+    // contiguous ranges: the top `panel_cus` mask bits for the panel, the rest for the update
+    // (an every-other-CU pattern was silently ignored by the dispatcher on this stack)
     int given = 0;
     for (int cu = 0; cu < ncu; ++cu) {
-        const bool to_panel = (stride > 0) && (cu % stride == stride - 1) && given < panel_cus;
-        if (to_panel) { mp[cu / 32] |= 1u << (cu % 32); ++given; }
+        if (cu >= ncu - panel_cus) { mp[cu / 32] |= 1u << (cu % 32); ++given; }
         else mu[cu / 32] |= 1u << (cu % 32);
     }
     if (given < panel_cus) { set_error("CU partition: cannot give %d CUs to the panel", panel_cus); return LSX_ERR_ARG; }
@@ -125,8 +125,10 @@ static int ensure_partition(lsx_handle_t h, int panel_cus) {
     return LSX_OK;
 }
 
+// k0 = first column handled here (columns < k0 were factored by the sequential driver).
 template <typename T>
-static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv) {
+static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv,
+                           int k0) {
     const int nb = h->nb;
     struct OnSide {  // launches inside this scope go to the given stream
         lsx_handle_t h; hipStream_t keep;
@@ -137,12 +139,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     hipStream_t main_s = h->stream, side = h->side_stream;
     const bool partitioned = h->lookahead == 2;
     if (partitioned) {
-        // the panel's workgroups (128 rows each in the tall-panel shape) all need a CU of their own
-        int want = (n + 127) / 128;
-        want = want < 16 ? 16 : want;
-        if (want * 2 > h->num_cu) want = h->num_cu / 2;
-        int pcus = 16;
-        while (pcus < want) pcus *= 2;
+        // the panel's workgroups (128 rows each) all need a CU of their own inside the panel's CU
+        // set; one and a half times as many CUs as workgroups are reserved, in multiples of 32
+        const int G = (n - k0 + 127) / 128;
+        int pcus = ((G + G / 2 + 31) / 32) * 32;
+        if (pcus > h->num_cu / 2) pcus = h->num_cu / 2;
+        if (pcus < G) { set_error("look-ahead partition: %d workgroups do not fit in %d CUs", G, pcus); return LSX_ERR_INTERNAL; }
+        if (const char *e = getenv("LSX_PANEL_CUS")) pcus = atoi(e);  // diagnostics: force the split
         LSX_TRY(ensure_partition(h, pcus));
         main_s = h->part_update;
         side = h->part_panel;
@@ -162,19 +165,29 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     // the side stream starts after everything already queued on the main stream (info memset, fills)
     LSX_HIP(hipEventRecord(h->ev_start, main_s));
     LSX_HIP(hipStreamWaitEvent(side, h->ev_start, 0));
+    // The gather list of panel p lives in moves_buf[p & 1]: panel p+1 (side stream) writes the other
+    // buffer while the update stream still applies panel p's interchanges to the left-hand columns,
+    // which nothing later depends on and which therefore run AFTER the big update, in its slack.
+    struct KeepMoves { lsx_handle_t h; ~KeepMoves() { h->moves = h->moves_buf[0]; } } keep_moves{h};
+    int step = 0;
     {
         OnSide g(h, side);
-        const int jb0 = n < nb ? n : nb;
-        LSX_TRY(launch_panel<T>(h, n, jb0, A, lda, 0, d_ipiv, d_info));
+        const int jb0 = (n - k0) < nb ? (n - k0) : nb;
+        h->moves = h->moves_buf[step & 1];
+        LSX_TRY(launch_panel<T>(h, n - k0, jb0, A + (size_t)k0 * lda + k0, lda, k0, d_ipiv + k0, d_info));
         LSX_HIP(hipEventRecord(h->ev_panel, side));
     }
-    for (int k = 0; k < n; k += nb) {
+    for (int k = k0; k < n; k += nb, ++step) {
         const int jb = (n - k < nb) ? n - k : nb;
         T *Akk = A + (size_t)k * lda + k;
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));  // panel k is factored
-        LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        const bool mv_valid = h->moves_valid;
+        h->moves = h->moves_buf[step & 1];
         const int rest = n - k - jb;
-        if (rest <= 0) break;
+        if (rest <= 0) {
+            LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
+            break;
+        }
         T *A12 = A + (size_t)k * lda + k + jb;
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
@@ -187,11 +200,18 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
         {
             OnSide g(h, side);
+            h->moves = h->moves_buf[(step + 1) & 1];
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
             LSX_HIP(hipEventRecord(h->ev_panel, side));
         }
+        const bool next_valid = h->moves_valid;
         if (rest > jb2)
             LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
+        // panel k's interchanges on the columns left of it, from panel k's own list
+        h->moves = h->moves_buf[step & 1];
+        h->moves_valid = mv_valid;
+        LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        h->moves_valid = next_valid;
     }
     if (partitioned) {  // hand the result back to the caller's stream
         LSX_HIP(hipEventRecord(h->ev_done, main_s));
@@ -213,12 +233,15 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
     T *Tinv = (T *)h->ws2;
     if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
-    if (h->lookahead && n > 2 * nb) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv);
-    // Two-level blocking: `kb` panels of width nb are factored back to back (each one updating
-    // only the remaining columns of its own super-block), then ONE trailing update of depth
-    // K = kb*nb follows.  The MFMA update moves C once per K: K = 256 halves its HBM traffic.
+    // Look-ahead (panel k+1 on its own CU set under the update of step k) pays where the panel chain
+    // dominates AND the update still has enough work to hide: measured on MI355X it wins ~9 % around
+    // n = 8192, loses a few % below ~6000 (the tall-panel shape and the split update cost more than
+    // is hidden) and is a wash above ~10000 (the update dominates; it needs all CUs).
+    constexpr int LOOKAHEAD_MIN = 7168, LOOKAHEAD_MAX = 10240;
+    int k_end = n;  // the sequential driver below handles columns [0, k_end)
+    if (h->lookahead && n >= LOOKAHEAD_MIN && n <= LOOKAHEAD_MAX && h->kblock == 1) k_end = 0;
     const int W = nb * h->kblock;
-    for (int k = 0; k < n; k += W) {
+    for (int k = 0; k < k_end; k += W) {
         const int w = (n - k < W) ? n - k : W;  // width of this super-block
         for (int j = 0; j < w; j += nb) {
             const int c = k + j;                      // first column of this panel
@@ -246,6 +269,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
                                        A + (size_t)(k + w) * lda + k + w, lda));
         }
     }
+    if (k_end < n) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end);
     return LSX_OK;
 }
 
@@ -478,7 +502,9 @@ int lsx_create(lsx_handle_t *out, int device) {
     int r = grow(&h->scratch, &h->scratch_bytes, 1 << 20);
     if (r == LSX_OK) {
         size_t mv = 0;
-        r = grow(&h->moves, &mv, 4096);
+        r = grow(&h->moves_buf[0], &mv, 8192);
+        h->moves_buf[1] = (char *)h->moves_buf[0] + 4096;
+        h->moves = h->moves_buf[0];
     }
     if (r != LSX_OK) { (void)hipStreamDestroy(h->own_stream); delete h; return r; }
     *out = h;
@@ -495,7 +521,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->scratch) (void)hipFree(h->scratch);
-    if (h->moves) (void)hipFree(h->moves);
+    if (h->moves_buf[0]) (void)hipFree(h->moves_buf[0]);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);

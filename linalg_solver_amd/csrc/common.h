@@ -67,7 +67,7 @@ struct lsx_handle_s {
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 1;  // 0 = per-column launches, 1 = cooperative kernel
-    int lookahead = 0;   // 1: factor panel k+1 on side_stream under the trailing update of step k
+    int lookahead = 2;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
@@ -81,7 +81,8 @@ struct lsx_handle_s {
     void *ws3 = nullptr;     // permutation vector + right-hand-side copy
     size_t ws3_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
-    void *moves = nullptr;      // int2[256]: gather list emitted by the cooperative panel kernel
+    void *moves = nullptr;      // int2[256]: gather list emitted by the cooperative panel kernel (current buffer)
+    void *moves_buf[2] = {nullptr, nullptr};  // the look-ahead driver alternates between two lists
     bool moves_valid = false;   // set by the last panel launch when `moves` describes its interchanges
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
     __shared__ T s_L[RB][8];          // block multipliers per row (0 where the row was already used)
     __shared__ T s_R[8][PB_COLS];     // the block's pivot rows, full width
 
+    // an earlier panel of this factorisation already failed (exchange time-out): do not spin again
+    if (info && *info < 0) return;
     const int G = gridDim.x, g = blockIdx.x;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;

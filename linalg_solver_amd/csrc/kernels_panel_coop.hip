@@ -127,6 +127,8 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb,
     // latency-critical and tiny: when the look-ahead driver runs this kernel beside the trailing
     // update, its waves must win issue arbitration against the co-resident MFMA waves
     __builtin_amdgcn_s_setprio(3);
+    // an earlier panel of this factorisation already failed (exchange time-out): do not spin again
+    if (info && *info < 0) return;
     const int G = gridDim.x, g = blockIdx.x;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int lane = tid & 63, wave = tid >> 6;

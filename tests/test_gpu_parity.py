@@ -167,7 +167,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     finally:
         h.set_option("panel_rt", 4)
         h.set_option("panel_nt", 0)
-        h.set_option("lookahead", 0)
+        h.set_option("lookahead", 2)
         h.set_option("kblock", 1)
     assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])
     # the blocked panel (mode 2) performs the same fused multiply-adds in the same order
@@ -523,6 +523,31 @@ def test_full_size_lu_invariants(dev, n, kind):
         Ainv = dev.getri(LU, ipiv)
         eye_err = float((A @ Ainv - torch.eye(n, dtype=torch.float64, device="cuda")).abs().max())
         assert eye_err < 1e-7, eye_err
+
+
+def test_lookahead_variants_are_bit_identical_at_8192(dev):
+    """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
+    reorders launches: the factors must not change by a single bit."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    n = 8192
+    A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    dev.fill_(A0, gen.U11, 4)
+    outs = []
+    try:
+        for look in (0, 1, 2):
+            dev.h.set_option("lookahead", look)
+            LU = A0.clone()
+            ipiv, info = dev.getrf_(LU)
+            torch.cuda.synchronize()
+            assert int(info.item()) == 0
+            outs.append((LU, ipiv.clone()))
+    finally:
+        dev.h.set_option("lookahead", 2)
+    for LU, ipiv in outs[1:]:
+        assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
 def test_full_size_fp32(dev):

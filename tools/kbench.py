@@ -125,7 +125,7 @@ def main():
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         dev.h.set_option("panel_nt", 0)
         dev.h.set_option("gemm_waves", 0)
-        for mode, rt, look, nb, kb in ((1, 4, 0, 128, 1), (1, 4, 2, 128, 1), (1, 4, 1, 128, 1)):
+        for mode, rt, look, nb, kb in ((1, 4, 2, 128, 1), (1, 4, 0, 128, 1)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
