@@ -114,6 +114,11 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda,
                  double *R, int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule);
 
+/* C (m x n) = A (m x k) * B (k x n) on the MFMA tile of the trailing update.  Replaces the numeric
+ * core of Matrix.__mul__ (linalg.py:101-158); used for residual checks A*x - b, A*inv(A) - I. */
+int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda, const double *B, int ldb,
+                   double *C, int ldc);
+
 /* ---- host-buffer entry points (fp32; BASELINE config 5) ------------------- */
 int lsx_getrf_f32(lsx_handle_t h, int n, float *A, int lda, int32_t *ipiv, int *info);
 int lsx_getrs_f32(lsx_handle_t h, int n, int nrhs, const float *LU, int lda,
@@ -153,6 +158,9 @@ int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int
                         int ldb);
 /* dC (m x n) -= dA (m x k) * dB (k x n) on the MFMA path. */
 int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
+                         const double *dB, int ldb, double *dC, int ldc);
+/* dC += dA * dB (same kernel, sign folded into the A operand). */
+int lsx_gemm_add_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
                          const double *dB, int ldb, double *dC, int ldc);
 int lsx_gemm_sub_f32_dev(lsx_handle_t h, int m, int n, int k, const float *dA, int lda,
                          const float *dB, int ldb, float *dC, int ldc);

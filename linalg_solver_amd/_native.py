@@ -59,6 +59,8 @@ _SIGS = {
     "lsx_trsm_lu_f64_dev": [_vp, _i, _i, _vp, _i, _vp, _i],
     "lsx_gemm_sub_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
     "lsx_gemm_sub_f32_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
+    "lsx_gemm_add_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
+    "lsx_matmul_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, _dp, _i],
     "lsx_fill_f64_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp, _dp],

@@ -308,6 +308,27 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
                      T *B, int ldb) {
     LSX_ARG(n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs && LU && d_ipiv && B);
     if (n == 0 || nrhs == 0) return LSX_OK;
+    // few right-hand sides: the solve-latency path (kernels_trsv.hip) works on 1, 2, 4 or 8 columns
+    const int nr = nrhs <= 1 ? 1 : nrhs <= 2 ? 2 : nrhs <= 4 ? 4 : 8;
+    if (nrhs <= 8 && n > 128) {
+        const size_t b64 = pad256((size_t)((n + 63) / 64) * 64 * 64 * sizeof(T));
+        const size_t b128 = pad256((size_t)((n + 127) / 128) * 128 * 128 * sizeof(T));
+        const size_t vec = pad256(sizeof(T) * (size_t)n * nr);
+        LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n) + 3 * vec));
+        LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * b64 + 2 * b128));
+        int32_t *perm = (int32_t *)h->ws3;
+        T *Bc = (T *)((char *)h->ws3 + pad256(sizeof(int32_t) * n));  // copy of B, zero-padded to nr columns
+        T *Bp = (T *)((char *)Bc + vec);                               // P * B, work space of the solve
+        T *X = (T *)((char *)Bp + vec);
+        LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
+        if (nr != nrhs) LSX_HIP(hipMemsetAsync(Bc, 0, sizeof(T) * (size_t)n * nr, h->stream));
+        LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nr));
+        LSX_TRY(launch_gather_rows<T>(h, n, nr, perm, Bc, nr, Bp, nr));
+        char *w = (char *)h->ws2;
+        LSX_TRY(lu_solve_few_rhs<T>(h, n, nr, LU, lda, Bp, nr, X, (T *)w, (T *)(w + b64), (T *)(w + 2 * b64),
+                                    (T *)(w + 2 * b64 + b128)));
+        return launch_copy2d<T>(h, n, nrhs, X, nr, B, ldb);
+    }
     // perm + a copy of B for the row gather
     LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n) + pad256(sizeof(T) * (size_t)n * nrhs)));
     int32_t *perm = (int32_t *)h->ws3;
@@ -315,16 +336,6 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
     LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
     LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nrhs));
     LSX_TRY(launch_gather_rows<T>(h, n, nrhs, perm, Bc, nrhs, B, ldb));
-    if ((nrhs == 1 || nrhs == 2 || nrhs == 4 || nrhs == 8) && n > 128) {
-        // solve-latency path: one launch per 128-row block step (kernels_trsv.hip)
-        const size_t b64 = pad256((size_t)((n + 63) / 64) * 64 * 64 * sizeof(T));
-        const size_t b128 = pad256((size_t)((n + 127) / 128) * 128 * 128 * sizeof(T));
-        LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * b64 + 2 * b128));
-        char *w = (char *)h->ws2;
-        LSX_TRY(lu_solve_few_rhs<T>(h, n, nrhs, LU, lda, B, ldb, Bc, (T *)w, (T *)(w + b64), (T *)(w + 2 * b64),
-                                    (T *)(w + 2 * b64 + b128)));
-        return launch_copy2d<T>(h, n, nrhs, Bc, nrhs, B, ldb);
-    }
     return lu_solve_permuted<T>(h, n, nrhs, LU, lda, B, ldb);
 }
 
@@ -683,6 +694,29 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
     return LSX_OK;
 }
 
+int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda, const double *B, int ldb,
+                   double *C, int ldc) {
+    LSX_ARG(h && m >= 0 && n >= 0 && k >= 0 && lda >= k && ldb >= n && ldc >= n);
+    if (m == 0 || n == 0) return LSX_OK;
+    LSX_ARG(C && (k == 0 || (A && B)));
+    const int la = ld_for(k > 0 ? k : 1), lb = ld_for(n), lc = ld_for(n);
+    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)m * la) + pad256(sizeof(double) * (size_t)(k > 0 ? k : 1) * lb) +
+                             pad256(sizeof(double) * (size_t)m * lc) + 512));
+    Carver c(h->ws);
+    double *dA = c.take<double>((size_t)m * la);
+    double *dB = c.take<double>((size_t)(k > 0 ? k : 1) * lb);
+    double *dC = c.take<double>((size_t)m * lc);
+    LSX_HIP(hipMemsetAsync(dC, 0, sizeof(double) * (size_t)m * lc, h->stream));
+    if (k > 0) {
+        LSX_TRY(h2d<double>(h, m, k, A, lda, dA, la));
+        LSX_TRY(h2d<double>(h, k, n, B, ldb, dB, lb));
+        LSX_TRY(launch_gemm_acc<double>(h, 1, m, n, k, dA, la, dB, lb, dC, lc));
+    }
+    LSX_TRY(d2h<double>(h, m, n, dC, lc, C, ldc));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
                  int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
     LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && rank);
@@ -770,6 +804,11 @@ int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, 
                          const double *dB, int ldb, double *dC, int ldc) {
     LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
     return launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
+}
+int lsx_gemm_add_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
+                         const double *dB, int ldb, double *dC, int ldc) {
+    LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
+    return launch_gemm_acc<double>(h, 1, m, n, k, dA, lda, dB, ldb, dC, ldc);
 }
 int lsx_gemm_sub_f32_dev(lsx_handle_t h, int m, int n, int k, const float *dA, int lda,
                          const float *dB, int ldb, float *dC, int ldc) {

@@ -67,7 +67,7 @@ struct lsx_handle_s {
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 1;  // 0 = per-column launches, 1 = cooperative kernel
-    int lookahead = 2;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets
+    int lookahead = 0;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets (+9 % at n~8192, bit-identical)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
@@ -136,6 +136,10 @@ int launch_fill(lsx_handle_t h, int kind, uint64_t seed, int m, int n, T *A, int
                 int col_off);
 template <typename T>
 int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
+                    T *C, int ldc);
+// C += A*B (plus = 1) or C -= A*B (plus = 0), same MFMA kernel
+template <typename T>
+int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
                     T *C, int ldc);
 template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,

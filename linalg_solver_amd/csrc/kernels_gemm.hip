@@ -60,7 +60,8 @@ constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) ban
 template <typename T, bool FULL, int NWN>
 __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__restrict__ A, int lda,
                                               const T *__restrict__ B, int ldb, T *__restrict__ C, int ldc,
-                                              int m0, int n0, T (*As)[BK][BM + LPAD], T (*Bs)[BK][BN + LPAD]) {
+                                              int m0, int n0, T (*As)[BK][BM + LPAD], T (*Bs)[BK][BN + LPAD],
+                                              int plus) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T v2 __attribute__((ext_vector_type(2)));
     constexpr int NT = 128 * NWN;      // threads
@@ -79,6 +80,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     const int a_row = tid >> 3, a_k = (tid & 7) * 2;
     const int b_k = tid >> 6, b_n = (tid & 63) * 2;
     T ra[NL][2], rb[NL][2];
+    const T sgn = plus ? T(1) : T(-1);
 
     auto load_slab = [&](int k0) {
         if (FULL) {
@@ -116,9 +118,9 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     const int bp0 = bperm(b_n), bp1 = bperm(b_n + 1);
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            As[buf][a_k][a_row + (NT / 8) * i] = -ra[i][0];
-            As[buf][a_k + 1][a_row + (NT / 8) * i] = -ra[i][1];
+        for (int i = 0; i < NL; ++i) {  // sign folded into A: the k-loop then accumulates C -+ A*B
+            As[buf][a_k][a_row + (NT / 8) * i] = sgn * ra[i][0];
+            As[buf][a_k + 1][a_row + (NT / 8) * i] = sgn * ra[i][1];
         }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
-                                                          int tiles_n, int tm_off, int tn_off) {
+                                                          int tiles_n, int tm_off, int tn_off, int plus) {
     __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M,
     const int tile_m = first_m + (bid % per_group) % gsize;
     const int tile_n = (bid % per_group) / gsize;
     const int m0 = (tile_m + tm_off) * BM, n0 = (tile_n + tn_off) * BN;
-    gemm_sub_tile<T, FULL, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs);
+    gemm_sub_tile<T, FULL, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, plus);
 }
 
 // Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
@@ -243,7 +245,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gemm_sub_skinny_kernel(int M, int N, int K,
                                                               const T *__restrict__ A, int lda,
                                                               const T *__restrict__ B, int ldb,
-                                                              T *__restrict__ C, int ldc) {
+                                                              T *__restrict__ C, int ldc, int plus) {
     // one wave per row of C: lanes split K, shuffle-reduce, lane j<N writes column j
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -263,19 +265,19 @@ __global__ __launch_bounds__(256) void gemm_sub_skinny_kernel(int M, int N, int 
             T v = part[j];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0 && j0 + j < N) C[(size_t)row * ldc + j0 + j] -= v;
+            if (lane == 0 && j0 + j < N) C[(size_t)row * ldc + j0 + j] += plus ? v : -v;
         }
     }
 }
 
 template <typename T>
-int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
+int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
                     T *C, int ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_GEMM, 2.0 * m * n * (double)k, 2.0 * sizeof(T) * m * (double)n);
     if (n < 16) {
         hipLaunchKernelGGL(gemm_sub_skinny_kernel<T>, dim3((m + 3) / 4), dim3(256), 0, h->stream, m,
-                           n, k, A, lda, B, ldb, C, ldc);
+                           n, k, A, lda, B, ldb, C, ldc, plus);
     } else {
         const int tm = (m + BM - 1) / BM, tn = (n + BN - 1) / BN;
         const int elems16 = 16 / (int)sizeof(T);
@@ -288,11 +290,11 @@ int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, co
             if (gm <= 0 || gn <= 0) return;
             const dim3 grid(gm * gn);
             if (waves == 8) {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
             } else {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on);
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
             }
         };
         go(true, fm, fn, 0, 0);                 // interior
@@ -303,6 +305,16 @@ int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, co
     return LSX_OK;
 }
 
+template <typename T>
+int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, const T *B, int ldb, T *C,
+                    int ldc) {
+    return launch_gemm_acc<T>(h, 0, m, n, k, A, lda, B, ldb, C, ldc);
+}
+
+template int launch_gemm_acc<double>(lsx_handle_t, int, int, int, int, const double *, int, const double *,
+                                     int, double *, int);
+template int launch_gemm_acc<float>(lsx_handle_t, int, int, int, int, const float *, int, const float *, int,
+                                    float *, int);
 template int launch_gemm_sub<double>(lsx_handle_t, int, int, int, const double *, int,
                                      const double *, int, double *, int);
 template int launch_gemm_sub<float>(lsx_handle_t, int, int, int, const float *, int, const float *,

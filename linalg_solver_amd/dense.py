@@ -139,6 +139,21 @@ def det(a, handle: Optional[N.Handle] = None) -> float:
         return s * math.inf
 
 
+def matmul(a, b, handle: Optional[N.Handle] = None) -> np.ndarray:
+    """C = A @ B on the MFMA tile of the trailing update (residual checks, Matrix.__mul__)."""
+    h = _h(handle)
+    A, B = _f64(a), _f64(b)
+    if A.ndim != 2 or B.ndim != 2 or A.shape[1] != B.shape[0]:
+        raise ValueError("Matrix dimensions must match")
+    m, k = A.shape
+    n = B.shape[1]
+    Cm = np.empty((m, n), dtype=np.float64)
+    if m and n:
+        N.check(h.lib.lsx_matmul_f64(h.ptr, m, n, k, _ptr(A, C.c_double), max(k, 1), _ptr(B, C.c_double), max(n, 1),
+                                     _ptr(Cm, C.c_double), n), "lsx_matmul_f64")
+    return Cm
+
+
 def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N.Handle] = None,
          pivot_rule: int = N.PIVOT_FIRST):
     """Reduced row echelon form over columns [0, bar_col).  Returns (R, pivots, rank).

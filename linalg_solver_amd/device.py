@@ -98,6 +98,17 @@ class DeviceSolver:
                    C.stride(0)), "gemm_sub_dev")
         return C
 
+    def gemm_add_(self, C: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
+        """C += A @ B (fp64) on the same kernel."""
+        for t, w in ((C, "C"), (A, "A"), (B, "B")):
+            _rowmajor(t, "gemm_add_ " + w)
+        m, k = A.shape
+        n = B.shape[1]
+        assert B.shape[0] == k and C.shape == (m, n) and C.dtype == torch.float64
+        N.check(self.lib.lsx_gemm_add_f64_dev(self.h.ptr, m, n, k, A.data_ptr(), A.stride(0), B.data_ptr(),
+                                              B.stride(0), C.data_ptr(), C.stride(0)), "gemm_add_dev")
+        return C
+
     def panel_(self, P: torch.Tensor, row0: int, ipiv: torch.Tensor, info: torch.Tensor):
         _rowmajor(P, "panel_")
         N.check(self.lib.lsx_panel_f64_dev(self.h.ptr, P.shape[0], P.shape[1], P.data_ptr(), P.stride(0), row0,

@@ -13,6 +13,7 @@ package replaces (citations are to /root/reference/linalg_solver/linalg.py):
     kernel()                           :749-756
     AffineSubspace / NoSolution        :491-532
     zero / identity / new_vector / transpose   :410-415, 483-489
+    __mul__ / scalar_mul / __neg__             :91-158 (matrix products on the MFMA tile)
 
 All arithmetic runs on the GPU through liblsx.so (dense.py -> _native.py).
 There is no CPU fallback: entries must be Python/numpy ints or floats, anything
@@ -121,6 +122,20 @@ class Matrix:
 
     def transpose(self) -> "Matrix":
         return Matrix([[self.items[j][i] for j in range(self.rows)] for i in range(self.cols)])
+
+    # ---- products (linalg.py:91-158): matrix x matrix on the GPU, scalars elementwise
+    def scalar_mul(self, scalar: Any) -> "Matrix":
+        return Matrix([[item * scalar for item in row] for row in self.items])  # linalg.py:91-92
+
+    def __neg__(self) -> "Matrix":
+        return self.scalar_mul(-1)
+
+    def __mul__(self, other) -> "Matrix":
+        if not isinstance(other, Matrix):
+            return self.scalar_mul(other)  # linalg.py:101-103
+        if self.cols != other.rows:
+            raise ValueError("Matrix dimensions must match")  # linalg.py:104-105
+        return Matrix(dense.matmul(_as_array(self.items), _as_array(other.items)).tolist())
 
     def cformat(self, _arg_of: str = "") -> str:
         body = r"\\".join(" & ".join(_fmt(v) for v in row) for row in self.items)

@@ -167,7 +167,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     finally:
         h.set_option("panel_rt", 4)
         h.set_option("panel_nt", 0)
-        h.set_option("lookahead", 2)
+        h.set_option("lookahead", 0)
         h.set_option("kblock", 1)
     assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])
     # the blocked panel (mode 2) performs the same fused multiply-adds in the same order
@@ -461,6 +461,25 @@ def test_rref_medium_against_exact(la):
         assert pivots2 == epiv and np.max(np.abs(R[:, :b] - want[:, :b])) < 1e-9
 
 
+def test_matrix_product_on_the_mfma_tile(la):
+    """Matrix.__mul__ (linalg.py:101-158) and the residual checks it is for."""
+    from linalg_solver_amd import dense, gen
+
+    rng = np.random.default_rng(12)
+    for m, k, n in ((3, 4, 2), (64, 64, 64), (130, 257, 65), (300, 1, 200), (1, 500, 1)):
+        A, B = rng.uniform(-1, 1, (m, k)), rng.uniform(-1, 1, (k, n))
+        assert np.max(np.abs(dense.matmul(A, B) - A @ B)) < 1e-12 * max(k, 1)
+    M1, M2 = la.Matrix([[1, 2], [3, 4]]), la.Matrix([[0.5, 0.0], [1.0, -1.0]])
+    assert (M1 * M2).items == [[2.5, -2.0], [5.5, -4.0]]
+    assert (M1 * 2).items == [[2, 4], [6, 8]] and (-M1).items == [[-1, -2], [-3, -4]]
+    with pytest.raises(ValueError, match="dimensions must match"):
+        la.Matrix([[1.0, 2.0]]) * la.Matrix([[1.0, 2.0]])
+    A = gen.fill(gen.U11, 9, 200, 200)
+    Ai = la.Matrix(A.tolist()).inverse()
+    P = np.array((la.Matrix(A.tolist()) * Ai).items)
+    assert np.max(np.abs(P - np.eye(200))) < 1e-10
+
+
 def test_kernel_and_underdetermined(la):
     A = [[1.0, 2.0, 3.0, 4.0], [2.0, 4.0, 6.0, 8.0], [1.0, 0.0, 1.0, 0.0]]
     ker = la.Matrix(A).kernel()
@@ -545,7 +564,7 @@ def test_lookahead_variants_are_bit_identical_at_8192(dev):
             assert int(info.item()) == 0
             outs.append((LU, ipiv.clone()))
     finally:
-        dev.h.set_option("lookahead", 2)
+        dev.h.set_option("lookahead", 0)
     for LU, ipiv in outs[1:]:
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
