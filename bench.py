@@ -90,12 +90,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # Rehearsal switch for a one-GPU box (not used by the driver): LSX_BENCH_REHEARSAL=1 runs every
+    # rank on GPU 0 over gloo with the panel broadcast staged through the host.
+    rehearsal = os.environ.get("LSX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from linalg_solver_amd import gen
     from linalg_solver_amd.device import DeviceSolver
@@ -129,7 +137,13 @@ def main():
     else:
         from linalg_solver_amd.dist import ShardedLU
 
-        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt)
+        bcast = None
+        if rehearsal:
+            def bcast(t, src):
+                hbuf = t.cpu()
+                dist.broadcast(hbuf, src=src)
+                t.copy_(hbuf)
+        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast)
         shards = [slu.fill(gen.U11, 1 + s) for s in range(total)]
 
         def step(i):
@@ -164,7 +178,7 @@ def main():
     dev.h.prof_enable(False)
     phases = dev.h.prof_read()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if world == 1:

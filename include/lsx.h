@@ -153,6 +153,13 @@ int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int ro
 /* Apply the jb interchanges (k-th: row row0+k <-> d_ipiv[k]) to ncols columns of dA. */
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
                       const int32_t *d_ipiv);
+/* The cooperative panel kernel also emits its interchanges as a gather list (256 x {dst, src}
+ * row pairs relative to row0, -1 = unused).  lsx_panel_moves_dev copies the list of the LAST
+ * lsx_panel_f64_dev call into d_moves (512 int32; *valid = 0 if that panel used the per-column
+ * kernels and produced no list); lsx_laswp_moves_f64_dev applies such a list to ncols columns.
+ * The multi-GPU driver ships the list inside the panel broadcast. */
+int lsx_panel_moves_dev(lsx_handle_t h, int32_t *d_moves, int *valid);
+int lsx_laswp_moves_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, const int32_t *d_moves);
 /* dB (jb x ncols) <- inv(L11) * dB with L11 the unit-lower jb x jb block at dL. */
 int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int ldl, double *dB,
                         int ldb);

@@ -57,6 +57,8 @@ _SIGS = {
     "lsx_panel_f64_dev": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "lsx_laswp_f64_dev": [_vp, _i, _vp, _i, _i, _i, _vp],
     "lsx_trsm_lu_f64_dev": [_vp, _i, _i, _vp, _i, _vp, _i],
+    "lsx_panel_moves_dev": [_vp, _vp, C.POINTER(_i)],
+    "lsx_laswp_moves_f64_dev": [_vp, _i, _vp, _i, _i, _vp],
     "lsx_gemm_sub_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
     "lsx_gemm_sub_f32_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],
     "lsx_gemm_add_f64_dev": [_vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i],

@@ -792,6 +792,21 @@ int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, 
     LSX_ARG(h && dA && d_ipiv && jb >= 0 && jb <= 256);
     return launch_laswp<double>(h, ncols, dA, lda, row0, jb, d_ipiv);
 }
+int lsx_panel_moves_dev(lsx_handle_t h, int32_t *d_moves, int *valid) {
+    LSX_ARG(h && d_moves && valid);
+    *valid = h->moves_valid ? 1 : 0;
+    if (h->moves_valid)
+        LSX_HIP(hipMemcpyAsync(d_moves, h->moves, 256 * 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, h->stream));
+    return LSX_OK;
+}
+int lsx_laswp_moves_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, const int32_t *d_moves) {
+    LSX_ARG(h && dA && d_moves);
+    void *keep = h->moves;
+    h->moves = (void *)d_moves;
+    const int r = launch_laswp_moves<double>(h, ncols, dA, lda, row0);
+    h->moves = keep;
+    return r;
+}
 int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int ldl, double *dB,
                         int ldb) {
     LSX_ARG(h && dL && dB && jb >= 1 && jb <= 256);

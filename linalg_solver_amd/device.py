@@ -119,6 +119,18 @@ class DeviceSolver:
         N.check(self.lib.lsx_laswp_f64_dev(self.h.ptr, A.shape[1], A.data_ptr(), A.stride(0), row0, jb,
                                            ipiv.data_ptr()), "laswp_dev")
 
+    def panel_moves_(self, moves: torch.Tensor) -> bool:
+        """Copy the gather list of the last panel_ call into `moves` (int32[512]); False if none."""
+        import ctypes as C
+        ok = C.c_int(0)
+        N.check(self.lib.lsx_panel_moves_dev(self.h.ptr, moves.data_ptr(), C.byref(ok)), "panel_moves_dev")
+        return bool(ok.value)
+
+    def laswp_moves_(self, A: torch.Tensor, row0: int, moves: torch.Tensor):
+        _rowmajor(A, "laswp_moves_")
+        N.check(self.lib.lsx_laswp_moves_f64_dev(self.h.ptr, A.shape[1], A.data_ptr(), A.stride(0), row0,
+                                                 moves.data_ptr()), "laswp_moves_dev")
+
     def trsm_lu_(self, L: torch.Tensor, B: torch.Tensor):
         _rowmajor(L, "trsm_lu_")
         _rowmajor(B, "trsm_lu_")

@@ -51,8 +51,10 @@ class ShardedLU:
             self.offset[b] = off
             off += self.widths[b]
         self.local_cols = off
-        # receive buffer for the broadcast: panel rows | pivots (as T) | info
-        self._buf = torch.empty((n * nb + nb + 1,), dtype=dtype, device=self.device)
+        # broadcast buffer: [gather list: 512 int32 = 256 T | has-list flag | info | pivots (as T) | panel rows]
+        self._buf = torch.zeros((258 + nb + n * nb,), dtype=dtype, device=self.device)
+        self._moves = self._buf[:256].view(torch.int32)  # raw int32 view of the first 2 KB
+        self._fast_swaps = hasattr(ops, "panel_moves_") and hasattr(ops, "laswp_moves_")
 
     # -- distribution helpers -------------------------------------------------
     def owner(self, b: int) -> int:
@@ -86,6 +88,17 @@ class ShardedLU:
         dist.all_reduce(full, group=self.group)  # disjoint supports: the sum is the union
         return full
 
+    def _has_list_host(self, buf, own) -> bool:
+        """Whether the broadcast carried a gather list.  The flag is known on the host without a
+        device read: the owner's panel kernel either always or never emits one for a given shape,
+        and every rank runs the same library -- so ask the local ops object once per shape."""
+        key = "list"
+        if not hasattr(self, "_list_cache"):
+            self._list_cache = {}
+        if key not in self._list_cache:
+            self._list_cache[key] = bool(buf[256].item() > 0.5)  # one sync, first step only
+        return self._list_cache[key]
+
     def _first_local_block_after(self, b: int) -> Optional[int]:
         for mb in self.my_blocks:
             if mb > b:
@@ -100,36 +113,46 @@ class ShardedLU:
         ops = self.ops
         ipiv = torch.zeros(n, dtype=torch.int32, device=self.device)
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._list_cache = {}
         for b in range(self.nblocks):
             k = b * nb
             jb = min(nb, n - k)
             m = n - k
             own = self.owner(b)
-            buf = self._buf[: m * jb + jb + 1]
-            panel = buf[: m * jb].view(m, jb)
+            buf = self._buf[: 258 + jb + m * jb]
+            panel = buf[258 + jb:].view(m, jb)
             if own == self.rank:
                 o = self.offset[b]
                 P = A[k:, o:o + jb]
                 ops.panel_(P, k, ipiv[k:k + jb], info)
                 panel.copy_(P)
-                buf[m * jb:m * jb + jb] = ipiv[k:k + jb].to(self.dtype)
-                buf[m * jb + jb] = info[0].to(self.dtype)
-            # the one exchange of the step: factored panel + pivots, owner -> everyone
+                buf[258:258 + jb].copy_(ipiv[k:k + jb])   # int32 -> T in one copy kernel
+                buf[257:258].copy_(info)
+                has_list = self._fast_swaps and ops.panel_moves_(self._moves)
+                buf[256:257].fill_(1.0 if has_list else 0.0)
+            # the one exchange of the step: factored panel + pivots (+ gather list), owner -> everyone
             self._bcast(buf, own)
             if own != self.rank:
-                ipiv[k:k + jb] = buf[m * jb:m * jb + jb].to(torch.int32)
-                info[0] = buf[m * jb + jb].to(torch.int32)
+                ipiv[k:k + jb].copy_(buf[258:258 + jb])   # exact: row indices < 2^53
+                info.copy_(buf[257:258])
             # interchanges on this rank's other columns (the owner's panel is already swapped)
             piv = ipiv[k:k + jb]
+            use_list = self._fast_swaps and self._has_list_host(buf, own)
+
+            def swap_rows(view):
+                if use_list:
+                    ops.laswp_moves_(view, k, self._moves)
+                else:
+                    ops.laswp_(view, k, jb, piv)
             nxt = self._first_local_block_after(b)
             left_cols = self.offset[b] if own == self.rank else (self.offset[nxt] if nxt is not None
                                                                   else self.local_cols)
             if left_cols > 0:
-                ops.laswp_(A[:, :left_cols], k, jb, piv)
+                swap_rows(A[:, :left_cols])
             if nxt is not None:
                 ro = self.offset[nxt]
                 right = A[:, ro:self.local_cols]
-                ops.laswp_(right, k, jb, piv)
+                swap_rows(right)
                 # U12 slice and trailing update of this rank's columns right of the panel
                 U12 = A[k:k + jb, ro:self.local_cols]
                 ops.trsm_lu_(panel[:jb, :], U12)
