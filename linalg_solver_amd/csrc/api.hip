@@ -571,7 +571,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
         LSX_ARG(value >= 16 && value <= 128 && value % 16 == 0);
         h->nb = value;
     } else if (!strcmp(key, "panel")) {
-        LSX_ARG(value >= 0 && value <= 2);
+        LSX_ARG(value >= 0 && value <= 3);
         h->panel_mode = value;
     } else if (!strcmp(key, "gemm_waves")) {
         LSX_ARG(value == 0 || value == 4 || value == 8);

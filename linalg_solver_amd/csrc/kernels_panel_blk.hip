@@ -55,13 +55,23 @@ struct __attribute__((aligned(16))) PbGran {
     unsigned pad;
 };
 
-template <typename T, int RT, int NT>
+template <typename T, int RT, int NT, bool DBG>
 __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, T *__restrict__ P, int ldp,
                                                                  int row0, int col0,
                                                                  int32_t *__restrict__ ipiv,
                                                                  int *__restrict__ info, char *recs,
                                                                  PbGran *rowbuf, int *status,
-                                                                 int2 *__restrict__ moves) {
+                                                                 int2 *__restrict__ moves,
+                                                                 unsigned long long *dbg) {
+    // DBG: stamped diagnostic build, wave 0 accumulates 100 MHz ticks per segment into dbg[g][0..7]
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+#define STAMP(i)                                                              \
+    if (DBG && (threadIdx.x >> 6) == 0) {                                     \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();      \
+        seg[i] += tn_ - tlast;                                                \
+        tlast = tn_;                                                          \
+    }
     constexpr int NTY = NT / 16;
     constexpr int RB = NTY * RT;
     __shared__ double s_cv[NTY];
@@ -140,7 +150,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
             s_cv[ty] = bv;
             s_ci[ty] = bi;
         }
+        STAMP(0)
         __syncthreads();
+        STAMP(1)
         constexpr int NCM = NTY < 64 ? NTY : 64;
         double wv = s_cv[lane & (NCM - 1)];
         int wi = s_ci[lane & (NCM - 1)];
@@ -193,6 +205,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
             }
         }
         if (tid == 64 && j > 0) replay(j - 1);
+        STAMP(2)
         // 3: wave 0 reads every workgroup's record (80 B each), all reduce to the same winner
         if (wave == 0 && G > 1) {
             double bv = -2.0;
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
                     __builtin_amdgcn_s_sleep(1);
                 }
             }
+            STAMP(3)
             // wave arg-max; remember which lane holds the winner's values
             double rv = bv;
             int ri = bi, rl = lane;
@@ -268,7 +282,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
                 if (lane == 0) atomicExch(status, 1);
             }
         }
+        STAMP(4)
         __syncthreads();
+        STAMP(5)
         // 4: the pivot is known: multipliers + rank-1 update INSIDE the block, bookkeeping
         const int wrow = s_win[1];
         const bool valid = s_win[2] != 0;
@@ -322,9 +338,11 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
                 for (int c = JC + 1; c < 8; ++c) a[r][c] -= l * u[c];
             }
         }
+        STAMP(6)
     };
 
     const int nblk = (jb + 7) / 8;
+    if (DBG) tlast = __builtin_amdgcn_s_memrealtime();
     for (int jt = 0; jt < nblk; ++jt) {
         const int j0 = 8 * jt;
 #pragma unroll
@@ -398,7 +416,11 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_blk_kernel(int m, int jb, 
                     for (int k = 0; k < 8; ++k) a[r][c] -= l[r][k] * U[k];
             }
         }
+        STAMP(7)
     }
+    if (DBG && tid == 0)
+        for (int i = 0; i < 8; ++i) dbg[g * 8 + i] = seg[i];
+#undef STAMP
     __syncthreads();
     if (tid == 0) replay(jb - 1);
     // a workgroup whose exchange timed out reports it through info (negative = protocol failure):
@@ -451,8 +473,16 @@ static int panel_blk_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp,
     char *recs = (char *)h->scratch + 256;
     PbGran *rowbuf = (PbGran *)((char *)h->scratch + 256 + rec_bytes);
     LSX_HIP(hipMemsetAsync(h->scratch, 0, need, h->stream));  // epoch / tag 0 never matches
-    hipLaunchKernelGGL((panel_blk_kernel<T, RT, NT>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp, row0, col0,
-                       d_ipiv, d_info, recs, rowbuf, status, (int2 *)h->moves);
+    if (h->panel_debug) {
+        const size_t dbg_off = (need + 255) & ~(size_t)255;
+        if (dbg_off + (size_t)G * 64 > h->scratch_bytes) { set_error("panel_blk: no room for stamps"); return LSX_ERR_INTERNAL; }
+        hipLaunchKernelGGL((panel_blk_kernel<T, RT, NT, true>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp, row0,
+                           col0, d_ipiv, d_info, recs, rowbuf, status, (int2 *)h->moves,
+                           (unsigned long long *)((char *)h->scratch + dbg_off));
+    } else {
+        hipLaunchKernelGGL((panel_blk_kernel<T, RT, NT, false>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp, row0,
+                           col0, d_ipiv, d_info, recs, rowbuf, status, (int2 *)h->moves, (unsigned long long *)nullptr);
+    }
     LSX_HIP(hipGetLastError());
     h->moves_valid = true;
     return LSX_OK;

@@ -38,14 +38,9 @@
 #include <type_traits>
 
 #include "common.h"
+#include "panel_xchg.h"
 
 namespace lsx {
-
-typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-
-constexpr int PC_COLS = 128;   // column capacity (16 thread columns x 8)
-constexpr int HDR_STRIDE = 512;  // bytes between headers: one line / channel each, not 16 B apart
-constexpr int SPIN_LIMIT = 1 << 20;   // ~1 s of polling before a workgroup gives up
 
 struct __attribute__((aligned(16))) XHdr {
     double val;          // |a| of the candidate, < 0: no candidate
@@ -59,12 +54,6 @@ __device__ __forceinline__ unsigned fold16(double v) {
     return (x ^ (x >> 16)) & 0xffffu;
 }
 
-struct __attribute__((aligned(16))) XGran {
-    unsigned long long bits;  // value (fp64 bits, or fp32 bits in the low half)
-    unsigned epoch;
-    unsigned pad;
-};
-
 // DBG = true builds the stamped diagnostic variant: wave 0 accumulates, per segment of
 // the column loop, 100 MHz wall-clock ticks into dbg[g][0..7] (never used for results).
 //
@@ -73,38 +62,6 @@ struct __attribute__((aligned(16))) XGran {
 // `switch` on the column made hipcc shuffle the tile through AGPRs: 1.3k v_accvgpr and
 // 370 branches, 5 us per column); conditionals on per-row state are selects, not
 // branches; the tile is RT x 8 with RT = 4 so the whole state stays in arch VGPRs.
-// ---- DPP cross-lane moves: VALU-rate, no trip through the LDS crossbar (ds_bpermute costs ~100+
-// cycles per dependent step).  Applied in the order quad xor 1, quad xor 2, row_half_mirror,
-// row_mirror they leave every lane of a 16-lane row with the row's reduction (max with ties).
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-    const int lo = dpp_i<CTRL>(__double2loint(v)), hi = dpp_i<CTRL>(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-#define LSX_DPP_STEP(CTRL, v, i)                                         \
-    {                                                                    \
-        const double ov_ = dpp_d<CTRL>(v);                               \
-        const int oi_ = dpp_i<CTRL>(i);                                  \
-        const bool b_ = (ov_ > v) | ((ov_ == v) & (oi_ < i));            \
-        v = b_ ? ov_ : v;                                                \
-        i = b_ ? oi_ : i;                                                \
-    }
-// arg-max (largest v, lowest i on ties) over each 16-lane row
-__device__ __forceinline__ void row16_argmax(double &v, int &i) {
-    LSX_DPP_STEP(0xB1, v, i)   // quad_perm [1,0,3,2]
-    LSX_DPP_STEP(0x4E, v, i)   // quad_perm [2,3,0,1]
-    LSX_DPP_STEP(0x141, v, i)  // row_half_mirror
-    LSX_DPP_STEP(0x140, v, i)  // row_mirror
-}
-__device__ __forceinline__ double readlane_d(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
 template <typename T, int RT, int NT, bool DBG>
 __global__ __launch_bounds__(NT, NT / 256) void panel_coop_kernel(int m, int jb, T *__restrict__ P, int ldp,
                                                             int row0, int col0,

@@ -1,0 +1,512 @@
+// Pipelined cooperative panel factorisation: the same one-launch, register-resident,
+// implicit-pivoting scheme as kernels_panel_coop.hip, re-cut so that the chain that limits a
+// column -- header visible -> winner known -> pivot row fetched -> multipliers -> next column
+// updated -> next candidate -> next header stored -- runs inside ONE wave with no LDS round
+// trip and no barrier on it.
+//
+// Reference loops covered: pivot search, row swap, scaling and elimination below the pivot for
+// jb consecutive pivots (linalg_solver/linalg.py:548-596).
+//
+// Layout.  Workgroup g owns panel rows [g*RB, (g+1)*RB), RB = NTY*RT, in registers: thread
+// (tx, ty) = (tid / NTY, tid % NTY) holds rows {NTY*r + ty} x columns {8*tx + c}.  The NTY
+// threads that own column j (tx == j>>3) are CONSECUTIVE LANES OF ONE WAVE, the "owner wave".
+//
+// Per column j:
+//   owner wave   reads the G headers of column j (one per lane; the first shot was issued at the end
+//                of the previous step), reduces to the winner (largest |a|, lowest row on ties) by
+//                fused-DPP integer reductions, fetches the winner's row (128
+//                self-validating 16-byte granules), broadcasts the 8 values it needs by readlane,
+//                forms the multipliers of its rows, applies them to the rest of its 8-column
+//                block, picks the candidate of column j+1 among its lanes (DPP again), stores the
+//                header of column j+1 (write-through), leaves row / multipliers / winner in LDS.
+//   barrier      one per column.
+//   all waves    apply the rank-1 update to the columns right of the owner block, freeze the pivot
+//                row, and the thread row holding the new candidate publishes it as granules --
+//                all of this while the next header exchange is in flight.
+// Every eighth column the next column lives in another thread column: its owner reads the
+// multipliers from LDS after the barrier and starts the chain there (one extra barrier).
+//
+// Arithmetic per element is the same sequence of fused multiply-adds as the other panel modes
+// (same multipliers from the same fast_recip), so the factors are bit-identical to theirs.
+// Every spin is bounded; a time-out sets *status and lets the grid drain.
+#include <type_traits>
+
+#include "common.h"
+#include "panel_xchg.h"
+
+namespace lsx {
+
+__device__ __forceinline__ double readlane_t(double v, int l) { return readlane_d(v, l); }
+__device__ __forceinline__ float readlane_t(float v, int l) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+// ---- reductions with the DPP move fused into the VALU op (v_max_u32_dpp / v_min_i32_dpp): one
+// instruction per step.  An arg-max over fp64 magnitudes is three such phases on the bit pattern
+// (non-negative doubles order like unsigned 64-bit integers): high word, low word, then the lowest
+// row index among the lanes that hold the maximum.
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    v = max(v, (unsigned)dpp_i<0xB1>((int)v));
+    v = max(v, (unsigned)dpp_i<0x4E>((int)v));
+    v = max(v, (unsigned)dpp_i<0x141>((int)v));
+    v = max(v, (unsigned)dpp_i<0x140>((int)v));
+    return v;
+}
+__device__ __forceinline__ int row16_min_i32(int v) {
+    v = min(v, dpp_i<0xB1>(v));
+    v = min(v, dpp_i<0x4E>(v));
+    v = min(v, dpp_i<0x141>(v));
+    v = min(v, dpp_i<0x140>(v));
+    return v;
+}
+// combine the 16-lane rows starting at lane0 (NROW of them) through scalar registers
+template <int NROW>
+__device__ __forceinline__ unsigned rows_max_u32(unsigned v, int lane0) {
+    unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, lane0);
+#pragma unroll
+    for (int k = 1; k < NROW; ++k) r = max(r, (unsigned)__builtin_amdgcn_readlane((int)v, lane0 + 16 * k));
+    return r;
+}
+template <int NROW>
+__device__ __forceinline__ int rows_min_i32(int v, int lane0) {
+    int r = __builtin_amdgcn_readlane(v, lane0);
+#pragma unroll
+    for (int k = 1; k < NROW; ++k) r = min(r, __builtin_amdgcn_readlane(v, lane0 + 16 * k));
+    return r;
+}
+// arg-max over NROW 16-lane rows starting at lane0: key = (khi, klo) bit pattern of |a| (0 for "no
+// candidate"), idx = row (INT_MAX for none).  Returns the winning row, wave-uniform; INT_MAX: none.
+// All 64 lanes must be active.
+template <int NROW>
+__device__ __forceinline__ int argmax_rows(unsigned khi, unsigned klo, int idx, int lane0) {
+    const unsigned mhi = rows_max_u32<NROW>(row16_max_u32(khi), lane0);
+    const bool top = khi == mhi;
+    const unsigned mlo = rows_max_u32<NROW>(row16_max_u32(top ? klo : 0u), lane0);
+    return rows_min_i32<NROW>(row16_min_i32((top & (klo == mlo)) ? idx : 0x7fffffff), lane0);
+}
+
+// KS = header slots per polling lane (G <= 64 * KS)
+template <typename T, int RT, int NT, int KS, bool DBG>
+__global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb, T *__restrict__ P, int ldp,
+                                                                  int row0, int col0,
+                                                                  int32_t *__restrict__ ipiv,
+                                                                  int *__restrict__ info, char *hdr,
+                                                                  XGran *xrow, int *status,
+                                                                  unsigned long long *dbg,
+                                                                  int2 *__restrict__ moves) {
+    constexpr int NTY = NT / 16;   // thread rows; the owners of one column are NTY consecutive lanes
+    constexpr int RB = NTY * RT;   // panel rows per workgroup
+    constexpr int NONE = 0x7fffffff;
+    static_assert(NTY == 16 || NTY == 32, "owner lanes must be one or two DPP rows of one wave");
+    __shared__ __attribute__((aligned(16))) T s_u[2][PC_COLS];   // pivot row of column j
+    __shared__ T s_l[2][RB];                                        // multipliers of column j
+    // x: winner row (-1 none), y: bit0 act, bit1 failed, z: next candidate (slice-local row, -1 none)
+    __shared__ __attribute__((aligned(16))) int4 s_info[2];
+    __shared__ int s_cl2;          // candidate chosen at a block boundary (slice-local row, -1 none)
+    __shared__ int s_hist[PC_COLS], s_topid[PC_COLS], s_postop[PC_COLS];
+    __shared__ int s_order[RB];
+
+    __builtin_amdgcn_s_setprio(3);
+    // an earlier panel of this factorisation already failed (exchange time-out): do not spin again
+    if (info && *info < 0) return;
+    const int G = gridDim.x, g = blockIdx.x;
+    const int tid = threadIdx.x, ty = tid % NTY, tx = tid / NTY;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int base = g * RB;
+
+    unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+#define STAMP(i)                                                              \
+    if (DBG) {                                                                \
+        const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();      \
+        seg[i] += tn_ - tlast;                                                \
+        tlast = tn_;                                                          \
+    }
+
+    __amdgpu_buffer_rsrc_t r_hdr = __builtin_amdgcn_make_buffer_rsrc(hdr, 0, 2 * G * HDR_STRIDE, 0x00020000);
+    __amdgpu_buffer_rsrc_t r_row =
+        __builtin_amdgcn_make_buffer_rsrc(xrow, 0, 2 * G * PC_COLS * (int)sizeof(XGran), 0x00020000);
+
+    // ---- load the slice (rows >= m and columns >= jb read as zero)
+    T a[RT][8];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int gi = base + NTY * r + ty;
+        const T *src = P + (size_t)gi * ldp + 8 * tx;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
+    }
+    for (int t = tid; t < PC_COLS; t += NT) { s_topid[t] = t; s_postop[t] = t; }
+    for (int t = tid; t < RB; t += NT) s_order[t] = -1;
+    unsigned frozen = 0;  // bit r: local row NTY*r+ty already used as a pivot (or outside the panel)
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+        if (base + NTY * r + ty >= m) frozen |= 1u << r;
+    bool failed = false;
+    // the header shot in flight for the column about to be processed, issued by its owner wave as the
+    // LAST vector-memory operation of its previous step.  Measured alternatives that lose: shots
+    // issued before the rank-1 update (hipcc guards the FMAs with a full vmcnt(0) while any load is
+    // outstanding, so the update stalls for the round trip), and a second staggered shot left
+    // unconsumed (same guard on the reuse of its registers).
+    u4 hA[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) hA[k] = u4{0u, 0u, 0u, 0u};
+    __syncthreads();
+
+    // replay of interchange jj on the position maps (one lane; LAPACK order bookkeeping)
+    auto replay = [&](int jj) __attribute__((always_inline)) {
+        const int c = s_hist[jj] & 0x3fffffff;
+        const bool zero_piv = (s_hist[jj] >> 30) & 1;
+        const int p = (c < jb) ? s_postop[c] : c;
+        const int d = s_topid[jj];
+        if (p != jj) {
+            s_topid[jj] = c;
+            if (p < jb) s_topid[p] = d;
+            s_postop[d] = p;
+            if (c < jb) s_postop[c] = jj;
+        }
+        if (g == 0) {
+            ipiv[jj] = row0 + p;
+            if (zero_piv && info && *info == 0) *info = col0 + jj + 1;
+        }
+    };
+
+    // one poll shot at the headers of column jn: lane q reads workgroups q, q+64, ...
+    auto shot = [&](u4(&h)[KS], const int jn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k)
+            h[k] = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, ((jn & 1) * G + lane + 64 * k) * HDR_STRIDE, 0, 16);
+        asm volatile("" ::: "memory");
+    };
+    // header of column jn: {|a| of the candidate (fp64 bits), row (-1: none), epoch jn+1}
+    auto store_header = [&](const int jn, const double val, const int row) __attribute__((always_inline)) {
+        const unsigned long long vb = (unsigned long long)__double_as_longlong(val);
+        u4 h;
+        h.x = (unsigned)vb; h.y = (unsigned)(vb >> 32); h.z = (unsigned)row; h.w = (unsigned)(jn + 1);
+        __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, ((jn & 1) * G + g) * HDR_STRIDE, 0, 16);
+    };
+    // the thread row holding slice-local row cl publishes it as granules of column jn
+    auto publish_row = [&](const int jn, const int cl_) __attribute__((always_inline)) {
+        const int cl = __builtin_amdgcn_readfirstlane(cl_);
+        if (cl < 0) return;
+        const int cr = cl / NTY;
+        if (ty == (cl % NTY)) {
+            const int off = ((((jn & 1) * G + g) * PC_COLS) + 8 * tx) * (int)sizeof(XGran);
+            u4 v;
+            v.z = (unsigned)(jn + 1);
+            v.w = 0u;
+#pragma unroll
+            for (int k = 0; k < RT; ++k)
+                if (cr == k) {  // scalar branch; the asm keeps hipcc from turning the chain into a
+                                // switch over a stack copy of the tile (tile in scratch for the whole kernel)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        T vk = a[k][c];
+                        asm volatile("" : "+v"(vk));
+                        unsigned long long bits;
+                        if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)vk);
+                        else bits = (unsigned long long)__float_as_uint((float)vk);
+                        v.x = (unsigned)bits;
+                        v.y = (unsigned)(bits >> 32);
+                        __builtin_amdgcn_raw_buffer_store_b128(v, r_row, off + 16 * c, 0, 16);
+                    }
+                }
+        }
+    };
+    // candidates of the owner lanes on register column CN, arg-max, header: runs in the owner wave
+    // with all lanes active.  Returns the slice-local candidate row (-1: none), wave-uniform.
+    auto choose_and_announce = [&](auto CNt, const int jn, const bool own, const int lane0)
+                                   __attribute__((always_inline)) -> int {
+        constexpr int CN = decltype(CNt)::value;
+        double nv = -1.0;
+        int ni = NONE;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const double av = fabs((double)a[r][CN]);
+            const int gi = base + NTY * r + ty;
+            const bool better = own & (((frozen >> r) & 1u) == 0u) & ((av > nv) | ((av == nv) & (gi < ni)));
+            nv = better ? av : nv;
+            ni = better ? gi : ni;
+        }
+        const bool mine = ni != NONE;
+        const unsigned long long kb = mine ? (unsigned long long)__double_as_longlong(nv) : 0ull;
+        const int win = argmax_rows<NTY / 16>((unsigned)(kb >> 32), (unsigned)kb, ni, lane0);
+        const bool have = win != NONE;
+        const int cl = have ? win - base : -1;
+        // the lane that holds the winning row announces it (its nv is that row's |a|); lane0 if none
+        if (have ? (own & (ni == win)) : (lane == lane0)) store_header(jn, have ? nv : 0.0, have ? win : -1);
+        return cl;
+    };
+    // start of an 8-column block: column jn (jn & 7 == 0) is up to date in its owner threads
+    auto block_start = [&](const int jn) __attribute__((always_inline)) {
+        const int txn = jn >> 3;
+        const int wn = (txn * NTY) >> 6, lane0 = (txn * NTY) & 63;
+        if (wave == wn) {
+            const int cl = choose_and_announce(std::integral_constant<int, 0>{}, jn, tx == txn, lane0);
+            if (lane == 0) s_cl2 = cl;
+        }
+        __syncthreads();
+        publish_row(jn, s_cl2);
+        if (wave == wn) shot(hA, jn);
+    };
+
+    // one column; JC = j & 7 is a compile-time constant
+    auto column = [&](auto JCt, const int j) __attribute__((always_inline)) {
+        constexpr int JC = decltype(JCt)::value;
+        const int par = j & 1;
+        const int txo = j >> 3;
+        const int wo = (txo * NTY) >> 6, lane0 = (txo * NTY) & 63;
+        const bool more = j + 1 < jb;
+        if (wave == wo) {
+            if (DBG && JC == 0) tlast = __builtin_amdgcn_s_memrealtime();
+            // ---------------- O1: all headers of column j (two shots are already in flight)
+            double bv = -1.0;
+            int bi = NONE;
+            bool failed_now = failed;
+            if (!failed) {
+                unsigned pend = 0;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    if (lane + 64 * k < G) pend |= 1u << k;
+                auto absorb = [&](u4(&h)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        const bool ok = (((pend >> k) & 1u) != 0u) & (h[k].w == (unsigned)(j + 1));
+                        const double hv = __longlong_as_double((long long)(((unsigned long long)h[k].y << 32) | h[k].x));
+                        const int hi = (int)h[k].z;
+                        const bool better = ok & (hi >= 0) & ((hv > bv) | ((hv == bv) & (hi < bi)));
+                        bv = better ? hv : bv;
+                        bi = better ? hi : bi;
+                        pend = ok ? (pend & ~(1u << k)) : pend;
+                    }
+                };
+                absorb(hA);
+                int spins = 0;
+                while (__any(pend != 0u)) {
+                    shot(hA, j);
+                    absorb(hA);
+                    if (++spins > SPIN_LIMIT) { failed_now = true; break; }
+                }
+            }
+            const unsigned long long kb = (bi != NONE) ? (unsigned long long)__double_as_longlong(bv) : 0ull;
+            const int win = argmax_rows<4>((unsigned)(kb >> 32), (unsigned)kb, bi, 0);
+            STAMP(0)
+            // ---------------- O2: the winner's row (granules lane and lane + 64)
+            const bool valid = (win != NONE) & !failed_now;
+            const int bg = valid ? win / RB : 0;
+            T u0 = T(0), u1 = T(0);
+            if (valid) {
+                const int roff = (par * G + bg) * PC_COLS * (int)sizeof(XGran);
+                int spins = 0;
+                for (;;) {
+                    const u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * lane, 0, 16);
+                    const u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * (lane + 64), 0, 16);
+                    asm volatile("" ::: "memory");
+                    if (!__any((v0.z != (unsigned)(j + 1)) | (v1.z != (unsigned)(j + 1)))) {
+                        if (sizeof(T) == 8) {
+                            u0 = (T)__longlong_as_double((long long)(((unsigned long long)v0.y << 32) | v0.x));
+                            u1 = (T)__longlong_as_double((long long)(((unsigned long long)v1.y << 32) | v1.x));
+                        } else {
+                            u0 = (T)__uint_as_float(v0.x);
+                            u1 = (T)__uint_as_float(v1.x);
+                        }
+                        break;
+                    }
+                    if (++spins > SPIN_LIMIT) { failed_now = true; break; }
+                }
+            }
+            s_u[par][lane] = u0;
+            s_u[par][lane + 64] = u1;
+            STAMP(1)
+            // ---------------- O3: multipliers, the rest of the owner block, next candidate, next header
+            const int ub = (8 * txo) & 63;
+            const T usrc = (txo >= 8) ? u1 : u0;
+            T uu[8];
+#pragma unroll
+            for (int c = JC; c < 8; ++c) uu[c] = readlane_t(usrc, ub + c);
+            const T piv = uu[JC];
+            const bool act = valid & !failed_now & (piv != T(0));
+            const T rinv = act ? fast_recip<T>(piv) : T(0);
+            const bool own = tx == txo;
+            if (own) {
+                if (valid && bg == g) {
+                    const int wl = win - base;
+                    if ((wl % NTY) == ty) frozen |= 1u << ((wl / NTY) & 31);
+                }
+                T l[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const T v = a[r][JC] * rinv;
+                    l[r] = ((frozen >> r) & 1u) ? T(0) : v;
+                    s_l[par][NTY * r + ty] = l[r];
+                    a[r][JC] = (act & (((frozen >> r) & 1u) == 0u)) ? l[r] : a[r][JC];
+                }
+                if (act) {
+#pragma unroll
+                    for (int c = JC + 1; c < 8; ++c)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) a[r][c] -= l[r] * uu[c];
+                }
+            }
+            STAMP(2)
+            int cl = -1;
+            if (JC < 7 && more)
+                cl = choose_and_announce(std::integral_constant<int, (JC < 7 ? JC + 1 : 7)>{}, j + 1, own, lane0);
+            if (lane == 0) s_info[par] = make_int4(valid ? win : -1, (act ? 1 : 0) | (failed_now ? 2 : 0), cl, 0);
+            if (failed_now && !failed && lane == 0) atomicExch(status, 1);
+            STAMP(3)
+        }
+        __syncthreads();
+        if (wave == wo) STAMP(4)
+        // ---------------- everyone: bookkeeping, rank-1 update right of the owner block, row publication
+        const int4 inf = s_info[par];
+        const int wrow = inf.x;
+        const bool act = (inf.y & 1) != 0;
+        failed |= (inf.y & 2) != 0;
+        const bool valid = wrow >= 0;
+        const bool next_here = JC < 7 && more;   // the next column has the same owner wave
+        if (tid == NT - 1) {
+            s_hist[j] = valid ? (wrow | (act ? 0 : (1 << 30))) : j;
+            if (j > 0) replay(j - 1);
+        }
+        if (valid && (wrow / RB) == g) {
+            const int wl = wrow - base;
+            if ((wl % NTY) == ty) {
+                frozen |= 1u << ((wl / NTY) & 31);
+                if (tx == 0) s_order[wl] = j;
+            }
+        }
+        if (act && tx > txo) {
+            T l[RT], u[8];
+#pragma unroll
+            for (int r = 0; r < RT; ++r) l[r] = s_l[par][NTY * r + ty];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) u[c] = s_u[par][8 * tx + c];
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a[r][c] -= l[r] * u[c];
+        }
+        if (next_here) publish_row(j + 1, inf.z);
+        if (next_here && wave == wo) shot(hA, j + 1);
+        if (wave == wo) STAMP(5)
+        if (JC == 7 && more) {
+            block_start(j + 1);
+            if (wave == wo) STAMP(6)
+        }
+    };
+
+    block_start(0);
+    for (int j0 = 0; j0 < jb; j0 += 8) {
+#define COL(k) if (j0 + k < jb) column(std::integral_constant<int, k>{}, j0 + k);
+        COL(0) COL(1) COL(2) COL(3) COL(4) COL(5) COL(6) COL(7)
+#undef COL
+    }
+    if (DBG && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&dbg[g * 8 + i], seg[i]);
+#undef STAMP
+    __syncthreads();
+    if (tid == NT - 1) replay(jb - 1);
+    // a workgroup whose exchange timed out reports it through info (negative = protocol failure):
+    // the host entry points turn that into LSX_ERR_INTERNAL instead of returning garbage factors
+    if (failed && info && lane == 0) atomicMin(info, -0x40000000);
+    __syncthreads();
+    // ---- the same permutation as a gather list for the columns outside the panel:
+    // final[row0 + dst] = old[row0 + src]; slot j: pivot j, slot PC_COLS + d: displaced top row d
+    if (g == 0 && moves) {
+        for (int t = tid; t < 2 * PC_COLS; t += NT) {
+            int dst = -1, src = -1;
+            if (t < jb) {
+                dst = t;
+                src = s_hist[t] & 0x3fffffff;
+            } else if (t >= PC_COLS && t - PC_COLS < jb) {
+                const int d = t - PC_COLS;
+                bool is_pivot = false;
+                for (int q = 0; q < jb; ++q) is_pivot |= ((s_hist[q] & 0x3fffffff) == d);
+                if (!is_pivot) { dst = s_postop[d]; src = d; }
+            }
+            if (dst == src) dst = src = -1;
+            moves[t] = make_int2(dst, src);
+        }
+    }
+    // ---- every row straight to its final (LAPACK-order) position
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        const int lr = NTY * r + ty;
+        const int gi = base + lr;
+        if (gi < m) {
+            const int ord = s_order[lr];
+            const int dest = ord >= 0 ? ord : (gi < jb ? s_postop[gi] : gi);
+            T *dst = P + (size_t)dest * ldp + 8 * tx;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (8 * tx + c < jb) dst[c] = a[r][c];
+        }
+    }
+}
+
+template <typename T, int RT, int NT, int KS>
+static int panel_pipe_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp, int row0, int col0,
+                             int32_t *d_ipiv, int *d_info) {
+    // exchange area in scratch: status | headers[2][G] (HDR_STRIDE apart) | granule rows[2][G][128]
+    const size_t hdr_bytes = (size_t)2 * G * HDR_STRIDE;
+    const size_t need = 256 + hdr_bytes + (size_t)2 * G * PC_COLS * sizeof(XGran);
+    const size_t dbg_off = (need + 255) & ~(size_t)255;
+    const size_t total = dbg_off + (h->panel_debug ? (size_t)G * 64 : 0);
+    if (total > h->scratch_bytes) {
+        set_error("panel_pipe: scratch too small (%zu > %zu)", total, h->scratch_bytes);
+        return LSX_ERR_INTERNAL;
+    }
+    int *status = (int *)h->scratch;
+    char *hdr = (char *)h->scratch + 256;
+    XGran *xrow = (XGran *)((char *)h->scratch + 256 + hdr_bytes);
+    // status word, headers AND granules are zeroed before EVERY launch: epoch 0 never matches
+    LSX_HIP(hipMemsetAsync(h->scratch, 0, h->panel_debug ? total : need, h->stream));
+    if (h->panel_debug) {
+        unsigned long long *dbg = (unsigned long long *)((char *)h->scratch + dbg_off);
+        hipLaunchKernelGGL((panel_pipe_kernel<T, RT, NT, KS, true>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves);
+    } else {
+        hipLaunchKernelGGL((panel_pipe_kernel<T, RT, NT, KS, false>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, (unsigned long long *)nullptr,
+                           (int2 *)h->moves);
+    }
+    LSX_HIP(hipGetLastError());
+    h->moves_valid = true;
+    return LSX_OK;
+}
+
+// Returns 1 when the shape is outside what the kernel supports (caller falls back).
+template <typename T>
+int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv,
+                    int *d_info) {
+    if (jb > PC_COLS) return 1;
+    // workgroup shape: NT threads (16 thread columns x NT/16 thread rows), RT rows per thread.  One
+    // wave per SIMD (NT = 256) keeps the critical wave's issue slots to itself; taller panels take
+    // 512 threads so that every workgroup is still resident at once.
+    int nt = h->panel_nt, rt = h->panel_rt;
+    auto rows = [](int nt_, int rt_) { return nt_ / 16 * rt_; };
+    auto wgs = [&](int nt_, int rt_) { return (m + rows(nt_, rt_) - 1) / rows(nt_, rt_); };
+    if (h->panel_nt == 0) {
+        nt = 256, rt = 4;
+        if (wgs(nt, rt) > 128) nt = 512;
+    }
+    if (nt != 256 && nt != 512) return 1;
+    if (wgs(nt, rt) > h->num_cu) { nt = 512; rt = 8; }  // 256-row slices
+    const int G = wgs(nt, rt);
+    if (G > h->num_cu || G > 256) return 1;
+    const int ks = G <= 64 ? 1 : (G <= 128 ? 2 : 4);
+#define LSX_PP(RT_, NT_, KS_)                     \
+    if (rt == RT_ && nt == NT_ && ks == KS_)      \
+        return panel_pipe_launch<T, RT_, NT_, KS_>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+    LSX_PP(4, 256, 1) LSX_PP(4, 256, 2) LSX_PP(4, 256, 4)
+    LSX_PP(4, 512, 1) LSX_PP(4, 512, 2) LSX_PP(4, 512, 4)
+    LSX_PP(8, 512, 1) LSX_PP(8, 512, 2) LSX_PP(8, 512, 4)
+#undef LSX_PP
+    return 1;
+}
+
+template int panel_pipelined<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);
+template int panel_pipelined<float>(lsx_handle_t, int, int, float *, int, int, int, int32_t *, int *);
+
+}  // namespace lsx

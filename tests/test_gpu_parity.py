@@ -136,7 +136,7 @@ def test_getrf_matches_cpu_twin(la, n):
     try:
         LU, ipiv, info = dense.lu_factor(A)
     finally:
-        h.set_option("panel", 1)
+        h.set_option("panel", 3)
     oLU, oipiv, oinfo = capi.getrf(A)
     assert info == oinfo == 0
     assert np.array_equal(ipiv, oipiv), "pivot sequence differs from the partial-pivot twin"
@@ -165,6 +165,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
             h.set_option("kblock", kb)
             results.append(dense.lu_factor(A))
     finally:
+        h.set_option("panel", 3)
         h.set_option("panel_rt", 4)
         h.set_option("panel_nt", 0)
         h.set_option("lookahead", 0)
@@ -175,8 +176,22 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
         h.set_option("panel", 2)
         LUb, ipivb, infob = dense.lu_factor(A)
     finally:
-        h.set_option("panel", 1)
+        h.set_option("panel", 3)
     assert infob == 0 and np.array_equal(ipivb, results[3][1]) and np.array_equal(LUb, results[3][0])
+    # ... and so does the pipelined panel (mode 3, the default) in every workgroup shape
+    try:
+        for nt, rt, look in ((0, 4, 0), (256, 4, 0), (512, 4, 0), (512, 8, 0), (0, 4, 1), (0, 4, 2)):
+            h.set_option("panel", 3)
+            h.set_option("panel_nt", nt)
+            h.set_option("panel_rt", rt)
+            h.set_option("lookahead", look)
+            LUp, ipivp, infop = dense.lu_factor(A)
+            assert infop == 0 and np.array_equal(ipivp, results[3][1]) and np.array_equal(LUp, results[3][0]), \
+                f"pipelined panel nt={nt} rt={rt} lookahead={look} differs"
+    finally:
+        h.set_option("panel_nt", 0)
+        h.set_option("panel_rt", 4)
+        h.set_option("lookahead", 0)
     # tile height and look-ahead do not change a single bit
     assert np.array_equal(results[1][1], results[0][1]) and np.array_equal(results[1][0], results[0][0])
     assert np.array_equal(results[2][1], results[3][1]) and np.array_equal(results[2][0], results[3][0])
@@ -190,7 +205,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     assert relerr(LU, oLU) < TOL64
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 @pytest.mark.parametrize("n", [16, 200, 513])
 def test_getrf_cooperative_panel_integer_and_singular(la, n, mode):
     from linalg_solver_amd import dense, gen
@@ -205,7 +220,7 @@ def test_getrf_cooperative_panel_integer_and_singular(la, n, mode):
         _, _, sinfo = dense.lu_factor(S)
         LU32, ipiv32, info32 = dense.lu_factor(A.astype(np.float32), dtype=np.float32)
     finally:
-        h.set_option("panel", 1)
+        h.set_option("panel", 3)
     assert info == 0 and _plu_residual(A, LU, ipiv) < 50 * n * 2.3e-16
     assert np.max(np.abs(np.tril(LU, -1))) <= 1.0
     assert sinfo == capi.getrf(S)[2] == 6

@@ -77,6 +77,72 @@ def main():
                 t = tmin - tcopy
                 print(f"panel mode={mode} nt={nt} rt={rt} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)  "
                       f"{2 * 8 * m * args.nb / t / 1e6:.1f} GB/s", flush=True)
+    if "panel3" in args.what:
+        import numpy as np
+        # pipelined panel (mode 3): bitwise check against mode 1, timing, then the stamped build
+        dev.h.set_option("panel_rt", 4)
+        for m in (args.n, args.n // 2, 1024, 384, 128, 100):
+            for nbw in (args.nb, 100):
+                P0 = torch.empty(m, nbw, dtype=torch.float64, device="cuda")
+                dev.fill_(P0, gen.U11, 3)
+                outs = []
+                for mode, nt in ((1, 0), (3, 0), (3, 512)):
+                    dev.h.set_option("panel", mode)
+                    dev.h.set_option("panel_nt", nt)
+                    P = P0.clone()
+                    ipiv = torch.zeros(nbw, dtype=torch.int32, device="cuda")
+                    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                    dev.panel_(P, 0, ipiv, info)
+                    torch.cuda.synchronize()
+                    outs.append((P, ipiv.clone(), int(info.item())))
+                for k in (1, 2):
+                    same = torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]) \
+                        and outs[0][2] == outs[k][2]
+                    print(f"panel3 check m={m} jb={nbw} variant={k}: {'bit-identical' if same else 'MISMATCH'} "
+                          f"info={outs[k][2]}", flush=True)
+        for mode, nt in ((1, 0), (3, 512), (3, 256)):
+            dev.h.set_option("panel", mode)
+            dev.h.set_option("panel_nt", nt)
+            for m in (args.n, args.n // 2, args.n // 8, 256):
+                P0 = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+                dev.fill_(P0, gen.U11, 3)
+                ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                P = P0.clone()
+
+                def run():
+                    P.copy_(P0)
+                    dev.panel_(P, 0, ipiv, info)
+                tmin, tmed = timeit(run, reps=5, warm=1)
+                tcopy, _ = timeit(lambda: P.copy_(P0), reps=5, warm=1)
+                t = tmin - tcopy
+                print(f"panel mode={mode} nt={nt} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)",
+                      flush=True)
+        names = ["O1:poll headers+winner", "O2:row granules", "O3:multipliers+block", "next cand+header",
+                 "barrier", "bulk+publish", "block boundary", "-"]
+        dev.h.set_option("panel", 3)
+        dev.h.set_option("panel_debug", 1)
+        for nt, m in ((512, args.n), (256, args.n), (512, 1024), (512, 128)):
+            dev.h.set_option("panel_nt", nt)
+            P = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+            ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                dev.fill_(P, gen.U11, 3)
+                dev.panel_(P, 0, ipiv, info)
+            torch.cuda.synchronize()
+            rows = nt // 16 * 4
+            G = (m + rows - 1) // rows
+            need = 256 + 2 * G * 512 + 2 * G * 128 * 16
+            off = (need + 255) & ~255
+            raw = np.frombuffer(dev.h.read_scratch(off, G * 64), dtype=np.uint64).reshape(G, 8).astype(np.float64)
+            us = raw / 100.0 / args.nb
+            print(f"stamps3 nt={nt} m={m} G={G}: owner-wave us per column (mean | max)   total {us.sum(1).mean():.2f}")
+            for i, nm in enumerate(names[:7]):
+                print(f"   {nm:24s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
+        dev.h.set_option("panel_debug", 0)
+        dev.h.set_option("panel_nt", 0)
+        dev.h.set_option("panel", 3)
     if "pmc" in args.what:
         # workload for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`: two kernels of known byte counts
         # (calibration) followed by the trailing-update kernel at LU-like shapes
@@ -116,6 +182,30 @@ def main():
             for i, nm in enumerate(names):
                 print(f"   {nm:22s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
         dev.h.set_option("panel_debug", 0)
+    if "stamps2" in args.what:
+        import numpy as np
+        names = ["1:candidates", "barrier A", "2:reduce+publish", "3:poll records", "3b:winner reduce+bcast",
+                 "barrier C", "4:multipliers+block update", "block end (per block/8)"]
+        dev.h.set_option("panel", 2)
+        dev.h.set_option("panel_debug", 1)
+        for m in (args.n, 1024, 128):
+            P = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+            ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                dev.fill_(P, gen.U11, 3)
+                dev.panel_(P, 0, ipiv, info)
+            torch.cuda.synchronize()
+            G = (m + 127) // 128
+            need = 256 + 2 * G * 256 + 2 * 8 * 128 * 16
+            off = (need + 255) & ~255
+            raw = np.frombuffer(dev.h.read_scratch(off, G * 64), dtype=np.uint64).reshape(G, 8).astype(np.float64)
+            us = raw / 100.0 / args.nb
+            print(f"stamps2 (blocked) m={m} G={G}: per-column us (mean | max)   total {us.sum(1).mean():.2f}")
+            for i, nm in enumerate(names):
+                print(f"   {nm:28s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
+        dev.h.set_option("panel_debug", 0)
+        dev.h.set_option("panel", 1)
     if "lu" in args.what:
         n = args.n
         A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
