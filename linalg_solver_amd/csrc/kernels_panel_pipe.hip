@@ -41,6 +41,19 @@ __device__ __forceinline__ float readlane_t(float v, int l) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
 }
 
+// Polling loads must be re-issued on every trip of a spin loop.  hipcc hoists a plain buffer load out
+// of a loop without stores (also with the "volatile" cache-policy bit), and an
+// `asm volatile("" ::: "memory")` fence keeps it in place only at the price of a full vmcnt(0) drain
+// right behind the load, which serialises every shot.  An opaque zero as the scalar offset does it
+// for free: the address looks different on every trip, and the waits stay exact.
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+constexpr int XLOAD = 16;  // sc1: device scope
+constexpr int PP_STAGGER = 4;  // s_sleep units (64 clk) between the two shots at a block start
+
 // ---- reductions with the DPP move fused into the VALU op (v_max_u32_dpp / v_min_i32_dpp): one
 // instruction per step.  An arg-max over fp64 magnitudes is three such phases on the bit pattern
 // (non-negative doubles order like unsigned 64-bit integers): high word, low word, then the lowest
@@ -123,6 +136,20 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         tlast = tn_;                                                          \
     }
 
+    // The pre-issued header shots and the row-publication stores are inline asm with a hand-counted
+    // s_waitcnt: hipcc's own wait insertion degrades to vmcnt(0) in this control flow, which would
+    // stall the rank-1 update behind the shots.  Raw buffer descriptors for the asm operands:
+    auto raw_desc = [](const void *p, unsigned bytes) __attribute__((always_inline)) {
+        const unsigned long long b = (unsigned long long)p;
+        u4 d;
+        d.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+        d.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) & 0xffffu;
+        d.z = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
+        d.w = 0x00020000u;
+        return d;
+    };
+    const u4 d_hdr = raw_desc(hdr, 2u * G * HDR_STRIDE);
+    const u4 d_row = raw_desc(xrow, 2u * G * PC_COLS * (unsigned)sizeof(XGran));
     __amdgpu_buffer_rsrc_t r_hdr = __builtin_amdgcn_make_buffer_rsrc(hdr, 0, 2 * G * HDR_STRIDE, 0x00020000);
     __amdgpu_buffer_rsrc_t r_row =
         __builtin_amdgcn_make_buffer_rsrc(xrow, 0, 2 * G * PC_COLS * (int)sizeof(XGran), 0x00020000);
@@ -143,14 +170,17 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
     for (int r = 0; r < RT; ++r)
         if (base + NTY * r + ty >= m) frozen |= 1u << r;
     bool failed = false;
-    // the header shot in flight for the column about to be processed, issued by its owner wave as the
-    // LAST vector-memory operation of its previous step.  Measured alternatives that lose: shots
-    // issued before the rank-1 update (hipcc guards the FMAs with a full vmcnt(0) while any load is
-    // outstanding, so the update stalls for the round trip), and a second staggered shot left
-    // unconsumed (same guard on the reuse of its registers).
-    u4 hA[KS];
+    // two header shots in flight for the column about to be processed, issued by its owner wave
+    // during its previous step: A right after the barrier, B after the rank-1 update, both BEFORE the
+    // row-publication stores (returns come back in issue order: a load queued behind write-through
+    // stores would wait for their acknowledgements).  Both are always consumed.
+    u4 hA[KS], hB[KS];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) hA[k] = u4{0u, 0u, 0u, 0u};
+    for (int k = 0; k < KS; ++k) { hA[k] = u4{0u, 0u, 0u, 0u}; hB[k] = u4{0u, 0u, 0u, 0u}; }
+    // explicit full drain of the tile loads: otherwise hipcc keeps the tile registers "possibly still
+    // loading" across the column loop (entry state merged into every trip) and guards the rank-1
+    // FMAs of EVERY column with vmcnt(0) -- which would wait for the pre-issued shots
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt/lgkmcnt untouched
     __syncthreads();
 
     // replay of interchange jj on the position maps (one lane; LAPACK order bookkeeping)
@@ -175,8 +205,26 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
     auto shot = [&](u4(&h)[KS], const int jn) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < KS; ++k)
-            h[k] = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, ((jn & 1) * G + lane + 64 * k) * HDR_STRIDE, 0, 16);
-        asm volatile("" ::: "memory");
+            h[k] = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, ((jn & 1) * G + lane + 64 * k) * HDR_STRIDE,
+                                                         opaque_zero(), XLOAD);
+    };
+    // the same shot, pre-issued: the compiler does not know the load is in flight; shots_wait() must
+    // run before h is read.  "+v" ties input and output so no copy of h is ever made in between.
+    auto shot_async = [&](u4(&h)[KS], const int jn) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            const int off = ((jn & 1) * G + lane + 64 * k) * HDR_STRIDE;
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "+v"(h[k]) : "v"(off), "s"(d_hdr));
+        }
+    };
+    // wait until the shots have landed: returns are in issue order and the operations this wave issued
+    // after its last shot are exactly the 8 granule stores of publish_row (always 8, see there), so
+    // "at most 8 outstanding" means both shots are complete without waiting for the stores'
+    // acknowledgements.  tools/check_panel_isa.py verifies on the built code object that nothing
+    // touches the shot registers between the asm loads and this wait.
+    auto shots_wait = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) asm volatile("s_waitcnt vmcnt(8)" : "+v"(hA[k]), "+v"(hB[k]));
     };
     // header of column jn: {|a| of the candidate (fp64 bits), row (-1: none), epoch jn+1}
     auto store_header = [&](const int jn, const double val, const int row) __attribute__((always_inline)) {
@@ -185,10 +233,11 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         h.x = (unsigned)vb; h.y = (unsigned)(vb >> 32); h.z = (unsigned)row; h.w = (unsigned)(jn + 1);
         __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, ((jn & 1) * G + g) * HDR_STRIDE, 0, 16);
     };
-    // the thread row holding slice-local row cl publishes it as granules of column jn
+    // the thread row holding slice-local row cl publishes it as granules of column jn.  ALWAYS
+    // exactly 8 store instructions per wave (every wave holds every thread row): without a candidate
+    // (cl < 0) row 0 is stored, which nobody fetches -- shots_wait() counts on the 8.
     auto publish_row = [&](const int jn, const int cl_) __attribute__((always_inline)) {
-        const int cl = __builtin_amdgcn_readfirstlane(cl_);
-        if (cl < 0) return;
+        const int cl = max(__builtin_amdgcn_readfirstlane(cl_), 0);
         const int cr = cl / NTY;
         if (ty == (cl % NTY)) {
             const int off = ((((jn & 1) * G + g) * PC_COLS) + 8 * tx) * (int)sizeof(XGran);
@@ -197,18 +246,21 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             v.w = 0u;
 #pragma unroll
             for (int k = 0; k < RT; ++k)
-                if (cr == k) {  // scalar branch; the asm keeps hipcc from turning the chain into a
-                                // switch over a stack copy of the tile (tile in scratch for the whole kernel)
+                if (cr == k) {  // scalar branch; the tile values go through asm operands, which also
+                                // keeps hipcc from turning the chain into a switch over a stack copy
+                                // of the tile (tile in scratch for the whole kernel)
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        T vk = a[k][c];
-                        asm volatile("" : "+v"(vk));
                         unsigned long long bits;
-                        if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)vk);
-                        else bits = (unsigned long long)__float_as_uint((float)vk);
+                        if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)a[k][c]);
+                        else bits = (unsigned long long)__float_as_uint((float)a[k][c]);
                         v.x = (unsigned)bits;
                         v.y = (unsigned)(bits >> 32);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, r_row, off + 16 * c, 0, 16);
+                        const int offc = off + 16 * c;
+                        // s_nop: a store wider than 64 bits reads its data registers for two more
+                        // cycles (hipcc pads its own stores; it does not look inside asm)
+                        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1"
+                                     : : "v"(v), "v"(offc), "s"(d_row));
                     }
                 }
         }
@@ -246,8 +298,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             if (lane == 0) s_cl2 = cl;
         }
         __syncthreads();
-        publish_row(jn, s_cl2);
-        if (wave == wn) shot(hA, jn);
+        const int cl2 = s_cl2;
+        if (wave == wn) { shot_async(hA, jn); __builtin_amdgcn_s_sleep(PP_STAGGER); shot_async(hB, jn); }
+        publish_row(jn, cl2);
     };
 
     // one column; JC = j & 7 is a compile-time constant
@@ -263,7 +316,10 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             double bv = -1.0;
             int bi = NONE;
             bool failed_now = failed;
-            if (!failed) {
+            {
+                // every shot is consumed on every path (also after a time-out): a load left pending
+                // on ANY path makes hipcc guard later reuse of its registers with a full vmcnt(0),
+                // which would stall the rank-1 update behind the shots of the next column
                 unsigned pend = 0;
 #pragma unroll
                 for (int k = 0; k < KS; ++k)
@@ -280,12 +336,14 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
                         pend = ok ? (pend & ~(1u << k)) : pend;
                     }
                 };
+                shots_wait();
                 absorb(hA);
-                int spins = 0;
+                absorb(hB);
+                int spins = failed ? SPIN_LIMIT : 0;
                 while (__any(pend != 0u)) {
+                    if (++spins > SPIN_LIMIT) { failed_now = true; break; }
                     shot(hA, j);
                     absorb(hA);
-                    if (++spins > SPIN_LIMIT) { failed_now = true; break; }
                 }
             }
             const unsigned long long kb = (bi != NONE) ? (unsigned long long)__double_as_longlong(bv) : 0ull;
@@ -299,9 +357,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
                 const int roff = (par * G + bg) * PC_COLS * (int)sizeof(XGran);
                 int spins = 0;
                 for (;;) {
-                    const u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * lane, 0, 16);
-                    const u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * (lane + 64), 0, 16);
-                    asm volatile("" ::: "memory");
+                    const int oz = opaque_zero();
+                    const u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * lane, oz, XLOAD);
+                    const u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r_row, roff + 16 * (lane + 64), oz, XLOAD);
                     if (!__any((v0.z != (unsigned)(j + 1)) | (v1.z != (unsigned)(j + 1)))) {
                         if (sizeof(T) == 8) {
                             u0 = (T)__longlong_as_double((long long)(((unsigned long long)v0.y << 32) | v0.x));
@@ -365,7 +423,10 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         failed |= (inf.y & 2) != 0;
         const bool valid = wrow >= 0;
         const bool next_here = JC < 7 && more;   // the next column has the same owner wave
-        if (tid == NT - 1) {
+        if (next_here && wave == wo) shot_async(hA, j + 1);
+        // bookkeeping by a lane of the wave AFTER the owner wave: never on the critical wave, and its
+        // global accesses (ipiv, info) never queue behind the owner wave's shots
+        if (tid == ((((wo + 1) % (NT / 64)) << 6) | 63)) {
             s_hist[j] = valid ? (wrow | (act ? 0 : (1 << 30))) : j;
             if (j > 0) replay(j - 1);
         }
@@ -387,8 +448,8 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
 #pragma unroll
                 for (int c = 0; c < 8; ++c) a[r][c] -= l[r] * u[c];
         }
+        if (next_here && wave == wo) shot_async(hB, j + 1);
         if (next_here) publish_row(j + 1, inf.z);
-        if (next_here && wave == wo) shot(hA, j + 1);
         if (wave == wo) STAMP(5)
         if (JC == 7 && more) {
             block_start(j + 1);
