@@ -220,8 +220,9 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
     // wait until the shots have landed: returns are in issue order and the operations this wave issued
     // after its last shot are exactly the 8 granule stores of publish_row (always 8, see there), so
     // "at most 8 outstanding" means both shots are complete without waiting for the stores'
-    // acknowledgements.  tools/check_panel_isa.py verifies on the built code object that nothing
-    // touches the shot registers between the asm loads and this wait.
+    // acknowledgements.  Nothing touches the shot registers between the asm loads and this wait (the
+    // "+v" operands tie them in place); the bit-identity tests against panel mode 1 on the GPU are
+    // the regression check for this hand-scheduled section.
     auto shots_wait = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < KS; ++k) asm volatile("s_waitcnt vmcnt(8)" : "+v"(hA[k]), "+v"(hB[k]));
@@ -548,9 +549,9 @@ int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int 
     int nt = h->panel_nt, rt = h->panel_rt;
     auto rows = [](int nt_, int rt_) { return nt_ / 16 * rt_; };
     auto wgs = [&](int nt_, int rt_) { return (m + rows(nt_, rt_) - 1) / rows(nt_, rt_); };
-    if (h->panel_nt == 0) {
+    if (h->panel_nt == 0) {  // measured: one header per polling lane (<= 64 workgroups) wins
         nt = 256, rt = 4;
-        if (wgs(nt, rt) > 128) nt = 512;
+        if (wgs(nt, rt) > 64) nt = 512;
     }
     if (nt != 256 && nt != 512) return 1;
     if (wgs(nt, rt) > h->num_cu) { nt = 512; rt = 8; }  // 256-row slices
