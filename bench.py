@@ -291,6 +291,28 @@ def main():
             t_inv = time.perf_counter() - t0
             out["config3_inverse"] = {"getri_ms": t_inv * 1e3, "lu_plus_inverse_ms": t_inv * 1e3 + ms_per_step,
                                       "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9}
+    if world == 1 and not args.no_extras and args.dtype == "f64":
+        # config #1 (the reference's own CPU-runnable case): 64 x 64 ints in [-5,5] as floats + rhs through
+        # the Matrix surface -- fast path, traced path (reference-order arithmetic + step list) and traced
+        # path with every intermediate LaTeX matrix, which is what the reference spends 12.3 s on
+        import random as _random
+        import linalg_solver_amd as la
+        _random.seed(2026)
+        A1 = [[float(_random.randint(-5, 5)) for _ in range(64)] for _ in range(64)]
+        b1 = [float(_random.randint(-5, 5)) for _ in range(64)]
+        aug1 = la.Matrix([r + [v] for r, v in zip(A1, b1)])
+        res = {}
+        for key, kw in (("fast_ms", {}), ("traced_steps_ms", {"trace": "steps"}), ("traced_full_latex_ms", {"trace": True})):
+            best = 1e9
+            for _ in range(3):
+                t0 = time.perf_counter()
+                r1 = aug1.row_reduce(**kw)
+                best = min(best, time.perf_counter() - t0)
+            res[key] = best * 1e3
+            res[key.replace("_ms", "_steps")] = len(r1[3])
+        res["reference_python_s"] = 12.33
+        res["note"] = "reference figure measured in the build container (BASELINE.md); traced results are bit-identical to it"
+        out["config1_64"] = res
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
     else:

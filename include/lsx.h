@@ -113,6 +113,24 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
  * the largest magnitude (same pivot positions, better conditioning). */
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda,
                  double *R, int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule);
+/* Traced row reduction: Matrix.row_reduce in the reference's own operation order (exact-zero pivot
+ * test with first-non-zero row swap, normalise, eliminate below, separate backward pass;
+ * linalg.py:547-629) with one IEEE rounding per operation, so R, the pivots and the step log are
+ * bit-identical to the reference's float arithmetic.  steps receives *nsteps records of 4 int32
+ * {kind, a, b, 0}: kind 0 = S (rows a and b swapped, 1-based), 1 = N (pivot row a normalised),
+ * 2 = E below the pivot in column a, 3 = E above the pivot in column a (linalg.py:556-606, :624-628).
+ * If max_snaps > 0, snaps receives the dense m x n matrix after each of the first max_snaps steps
+ * (the reference's intermediate_matrices, linalg.py:553-555 etc.).  max_steps >= 4*min(m,bar_col)
+ * always suffices; LSX_ERR_ARG if the log is too small.  int_mask (m x n bytes, may be NULL = all
+ * floats) says on entry which entries are Python ints and on return which still are: the reference
+ * computes on Python objects, so int - int*int stays an int and only division or a float operand
+ * makes a float; snap_int_mask (max_snaps x m x n bytes) is the same per
+ * snapshot.  A host layer uses the masks to hand ints back.  The trace path is for small and medium inputs (several launches per column,
+ * HBM-bound); the fast paths are lsx_gesv_f64 / lsx_rref_f64. */
+int lsx_rref_trace_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
+                       int ldr, unsigned char *int_mask, int32_t *pivots, int *npivots, int32_t *steps,
+                       int max_steps, int *nsteps, double *snaps, unsigned char *snap_int_mask,
+                       int max_snaps);
 
 /* C (m x n) = A (m x k) * B (k x n) on the MFMA tile of the trailing update.  Replaces the numeric
  * core of Matrix.__mul__ (linalg.py:101-158); used for residual checks A*x - b, A*inv(A) - I. */

@@ -573,6 +573,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value >= 0 && value <= 3);
         h->panel_mode = value;
+    } else if (!strcmp(key, "gemm_stagger")) {
+        LSX_ARG(value >= 0 && value <= 64);
+        h->gemm_stagger = value;
     } else if (!strcmp(key, "gemm_waves")) {
         LSX_ARG(value == 0 || value == 4 || value == 8);
         h->gemm_waves = value;
@@ -605,6 +608,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "panel_rt")) *value = h->panel_rt;
     else if (!strcmp(key, "kblock")) *value = h->kblock;
     else if (!strcmp(key, "gemm_waves")) *value = h->gemm_waves;
+    else if (!strcmp(key, "gemm_stagger")) *value = h->gemm_stagger;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
@@ -770,6 +774,47 @@ int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int
                     double *d_out) {
     LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
     return launch_det<double>(h, n, dLU, lda, d_ipiv, d_out);
+}
+int lsx_rref_trace_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R, int ldr,
+                       unsigned char *int_mask, int32_t *pivots, int *npivots, int32_t *steps, int max_steps,
+                       int *nsteps, double *snaps, unsigned char *snap_int_mask, int max_snaps) {
+    LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && npivots && steps && nsteps);
+    LSX_ARG(max_steps >= 1 && max_snaps >= 0 && (max_snaps == 0 || (snaps && snap_int_mask)));
+    const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
+    LSX_ARG(bar <= n);
+    const int ld = ld_for(n);
+    const int np = m < n ? m : n;
+    const size_t snap_elems = (size_t)max_snaps * m * n;
+    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)m * ld) + pad256(sizeof(int32_t) * 2 * np) +
+                             pad256(sizeof(int32_t) * 4 * (size_t)max_steps) + pad256(sizeof(double) * snap_elems) +
+                             pad256(snap_elems) + pad256((size_t)m * n) + 1024));
+    LSX_TRY(ensure_scratch(h, 4096));
+    Carver c(h->ws);
+    double *dR = c.take<double>((size_t)m * ld);
+    int32_t *dp = c.take<int32_t>(2 * (size_t)np);
+    int32_t *ds = c.take<int32_t>(4 * (size_t)max_steps);
+    double *dsn = snap_elems ? c.take<double>(snap_elems) : nullptr;
+    unsigned char *dst = snap_elems ? c.take<unsigned char>(snap_elems) : nullptr;
+    unsigned char *dT = c.take<unsigned char>((size_t)m * n);
+    int *dout = c.take<int>(4);
+    LSX_TRY(h2d<double>(h, m, n, A, lda, dR, ld));
+    if (int_mask) LSX_HIP(hipMemcpyAsync(dT, int_mask, (size_t)m * n, hipMemcpyHostToDevice, h->stream));
+    else LSX_HIP(hipMemsetAsync(dT, 0, (size_t)m * n, h->stream));
+    LSX_TRY(launch_rref_trace(h, m, n, bar, dR, ld, dT, dp, ds, max_steps, dsn, dst, max_snaps, dout));
+    LSX_TRY(d2h<double>(h, m, n, dR, ld, R, ldr));
+    int out[3] = {0, 0, 0};
+    LSX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    *npivots = out[0];
+    *nsteps = out[1];
+    if (out[2]) { set_error("rref_trace: more than %d steps", max_steps); return LSX_ERR_ARG; }
+    if (out[0] > 0) LSX_HIP(hipMemcpy(pivots, dp, sizeof(int32_t) * 2 * out[0], hipMemcpyDeviceToHost));
+    if (out[1] > 0) LSX_HIP(hipMemcpy(steps, ds, sizeof(int32_t) * 4 * out[1], hipMemcpyDeviceToHost));
+    const int ns = out[1] < max_snaps ? out[1] : max_snaps;
+    if (ns > 0) LSX_HIP(hipMemcpy(snaps, dsn, sizeof(double) * (size_t)ns * m * n, hipMemcpyDeviceToHost));
+    if (ns > 0) LSX_HIP(hipMemcpy(snap_int_mask, dst, (size_t)ns * m * n, hipMemcpyDeviceToHost));
+    if (int_mask) LSX_HIP(hipMemcpy(int_mask, dT, (size_t)m * n, hipMemcpyDeviceToHost));
+    return LSX_OK;
 }
 int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
                      int32_t *d_pivots, int *d_rank, double tol, int pivot_rule) {

@@ -70,6 +70,7 @@ struct lsx_handle_s {
     int lookahead = 0;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets (+9 % at n~8192, bit-identical)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
+    int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     int num_cu = 256;
@@ -141,6 +142,10 @@ int launch_gemm_sub(lsx_handle_t h, int m, int n, int k, const T *A, int lda, co
 template <typename T>
 int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
                     T *C, int ldc);
+// traced reference-order row reduction (kernels_trace.hip); d_out = {pivots, steps, overflow}
+int launch_rref_trace(lsx_handle_t h, int m, int n, int bar, double *R, int ldr, unsigned char *Tm,
+                      int32_t *d_pivots, int32_t *d_steps, int max_steps, double *d_snaps,
+                      unsigned char *d_snap_t, int max_snaps, int *d_out);
 template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
                  int *d_info);

@@ -221,6 +221,17 @@ __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M,
     __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
+    // ---- optional phase stagger (option "gemm_stagger", default 0).  Two workgroups share a CU;
+    // launched together they run their memory-bound phases (C read, C write) and their MFMA phases in
+    // step.  Delaying the second resident wave of the grid by a fraction of a tile de-phases them;
+    // measured gain 2-4 % at K = 128, inside run-to-run noise, so it is off by default.
+    {
+        const int stagger = plus >> 8;
+        if (stagger > 0 && ((blockIdx.x >> 8) & 1))
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    plus &= 0xff;
+
     // ---- XCD-aware grouped tile order
     const int nwg = tiles_m * tiles_n;
     int bid = blockIdx.x;
@@ -290,11 +301,11 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
             if (gm <= 0 || gn <= 0) return;
             const dim3 grid(gm * gn);
             if (waves == 8) {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
             } else {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus);
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
             }
         };
         go(true, fm, fn, 0, 0);                 // interior

@@ -170,3 +170,43 @@ def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N
                                _ptr(piv, C.c_int32), C.byref(rank), float(tol), int(pivot_rule)), "lsx_rref_f64")
     r = rank.value
     return R, [(int(piv[2 * i]), int(piv[2 * i + 1])) for i in range(r)], r
+
+
+TRACE_KINDS = ("S", "N", "E", "E")   # step record kind -> label letter (swap, normalise, eliminate below / above)
+
+
+def rref_trace(a, bar_col: Optional[int] = None, max_snapshots: int = 0, int_mask=None,
+               handle: Optional[N.Handle] = None):
+    """Row reduction in the reference's own operation order with its step log (lsx_rref_trace_f64;
+    linalg.py:547-629).  Returns (R, pivots, steps, int_mask, snaps, snap_int_masks): steps is a list of
+    (kind, a, b) with kind 0 = swap rows a,b / 1 = normalise row a / 2 = eliminate below the pivot of
+    column a / 3 = eliminate above the pivot of column a (1-based, as in the reference's descriptions).
+    int_mask (bool m x n, default all False) says which input entries are Python ints; the returned mask
+    says which entries the reference would still hold as ints.  snaps / snap_int_masks hold the matrix
+    and its mask after each of the first max_snapshots steps (or None)."""
+    h = _h(handle)
+    A = _f64(a)
+    if A.ndim != 2 or A.shape[0] < 1 or A.shape[1] < 1:
+        raise ValueError("rref_trace needs a non-empty 2-D matrix")
+    m, n = A.shape
+    bar = int(bar_col or 0) or n - 1
+    max_steps = 4 * min(m, max(bar, 1)) + 4
+    R = np.empty_like(A)
+    mask = np.zeros((m, n), dtype=np.uint8)
+    if int_mask is not None:
+        mask[:, :] = np.asarray(int_mask, dtype=bool)
+    piv = np.zeros(2 * min(m, n) + 2, dtype=np.int32)
+    steps = np.zeros(4 * max_steps, dtype=np.int32)
+    nsnap = max(0, min(int(max_snapshots), max_steps))
+    snaps = np.empty((nsnap, m, n), dtype=np.float64) if nsnap else None
+    snap_m = np.zeros((nsnap, m, n), dtype=np.uint8) if nsnap else None
+    npiv, nsteps = C.c_int(0), C.c_int(0)
+    N.check(h.lib.lsx_rref_trace_f64(h.ptr, m, n, int(bar_col or 0), _ptr(A, C.c_double), n, _ptr(R, C.c_double), n,
+                                     mask.ctypes.data, _ptr(piv, C.c_int32), C.byref(npiv),
+                                     _ptr(steps, C.c_int32), max_steps, C.byref(nsteps),
+                                     _ptr(snaps, C.c_double) if nsnap else None,
+                                     snap_m.ctypes.data if nsnap else None, nsnap), "lsx_rref_trace_f64")
+    pivots = [(int(piv[2 * i]), int(piv[2 * i + 1])) for i in range(npiv.value)]
+    recs = [(int(steps[4 * i]), int(steps[4 * i + 1]), int(steps[4 * i + 2])) for i in range(nsteps.value)]
+    k = min(nsnap, nsteps.value)
+    return R, pivots, recs, mask.astype(bool), (snaps[:k] if nsnap else None), (snap_m[:k].astype(bool) if nsnap else None)

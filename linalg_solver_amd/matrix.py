@@ -200,22 +200,71 @@ class Matrix:
                 R = R1
         return R, pivots
 
-    def row_reduce(self, bar_col: int = None):
-        """linalg.py:534-630.  Returns (reduced_items, pivots, [], [])."""
+    # step descriptions of the reference's log (linalg.py:557-560, 580, 602-604, 626), verbatim: they are
+    # part of what row_reduce returns
+    _STEP_TEXT = (r"Výměna řádků $R_{%d}$ a $R_{%d}$", r"Normalizace pivotního řádku %s",
+                  r"Eliminace prvků pod pivotem ve sloupci %s", r"Eliminace nad pivotem ve sloupci %s")
+    TRACE_SNAPSHOT_BYTES = 256 << 20   # cap on the device memory spent on intermediate matrices
+
+    def row_reduce(self, bar_col: int = None, trace=False):
+        """linalg.py:534-630.  Returns (reduced_items, pivots, intermediate_matrices, intermediate_steps).
+
+        trace=False (default): the fast paths (blocked LU / rank-revealing RREF); the two logs are empty.
+        trace="steps": the reduction runs in the reference's own operation order on the device
+        (lsx_rref_trace_f64): reduced_items, pivots and the (label, description) list are identical to
+        the reference's, bit for bit; intermediate_matrices stays empty.
+        trace=True / "full": additionally the LaTeX of the matrix after every step (first = the initial
+        matrix, linalg.py:544), formatted like the reference's fmt.make_latex_augmented_matrix.  Meant
+        for small inputs, like the reference's own log; beyond TRACE_SNAPSHOT_BYTES of snapshots the
+        list is truncated to the first steps.
+        Entry types follow the reference's object arithmetic: ints stay ints until a division or a float
+        operand touches them (exact up to 2^53)."""
         A = _as_array(self.items)
         n = A.shape[1]
         if n == 0:
             raise IndexError("list index out of range")  # reference fails at len(A[0]) / A[0][0]
         bar = bar_col or n - 1  # :543 -- 0 and None both mean n-1
+        if trace:
+            return self._row_reduce_traced(A, bar, full=(trace != "steps"))
         R, pivots = self._reduce(A, min(bar, n))
         if bar > n and len(pivots) < A.shape[0]:
             # the reference walks pivot_j past the last column here (:548) and fails the same way
             raise IndexError("list index out of range")
         return R.tolist(), pivots, [], []
 
+    def _row_reduce_traced(self, A: np.ndarray, bar: int, full: bool):
+        from . import fmt
+        m, n = A.shape
+        if bar > n:
+            raise IndexError("list index out of range")  # the reference indexes A[pi][pj] with pj >= n (:548)
+        max_steps = 4 * min(m, bar) + 4
+        nsnap = min(max_steps, max(1, self.TRACE_SNAPSHOT_BYTES // (9 * m * n))) if full else 0
+        # the reference computes on Python objects: int - int*int stays an int (appendix A.2); the device
+        # carries that flag along with every entry
+        int_in = [[isinstance(v, (int, np.integer)) and not isinstance(v, bool) for v in row] for row in self.items]
+        R, pivots, recs, imask, snaps, snap_m = dense.rref_trace(A, bar, max_snapshots=nsnap, int_mask=int_in)
+
+        def typed(values, mask):
+            return [[int(values[i][j]) if mask[i][j] else float(values[i][j]) for j in range(n)] for i in range(m)]
+
+        steps, mats = [], []
+        if full:
+            mats.append(fmt.make_latex_augmented_matrix(self.items, bar_col=bar))
+        for k, (kind, a, b) in enumerate(recs):
+            text = self._STEP_TEXT[kind] % ((a, b) if kind == 0 else (a,))
+            steps.append((f"{dense.TRACE_KINDS[kind]}{k}", text))
+            if full and k < len(snaps):
+                mats.append(fmt.make_latex_augmented_matrix(typed(snaps[k], snap_m[k]), bar_col=bar))
+        return typed(R, imask), pivots, mats, steps
+
     def find_preimage_of(self, vec: List[Any], log_matrices: bool = False, log_steps: bool = False,
-                         log_result: bool = False) -> "Matrix.AffineSubspace | Matrix.NoSolution":
-        """All solutions of self * x = vec (linalg.py:632-680)."""
+                         log_result: bool = False, trace=False) -> "Matrix.AffineSubspace | Matrix.NoSolution":
+        """All solutions of self * x = vec (linalg.py:632-680).
+
+        The log_* flags select the reference's carrier shapes (:998 vs :888) on the fast path.  With
+        trace="steps" / True the reduction runs in the reference's own operation order instead (exact
+        zero tests, its float rank artefacts included) and `self.last_trace` = (matrices, steps) holds
+        what the reference would have written to its LaTeX log."""
         if self.rows != len(vec):
             raise ValueError("Matrix dimensions must match")  # :642-643
         logged = log_matrices or log_steps or log_result
@@ -225,6 +274,9 @@ class Matrix:
         if n == 0:
             raise IndexError("list index out of range")
         aug = np.hstack([A, b])
+        if trace:
+            typed_aug = [list(row) + [v] for row, v in zip(self.items, vec)]   # entry types matter there
+            return self._find_preimage_traced(typed_aug, n, full=(trace != "steps"))
         R, pivots = self._reduce(aug, n)
         # :913-934 with a tolerance on the right-hand side: rows below the rank have exact
         # zero coefficients; their rhs is rounding noise unless the system is inconsistent
@@ -254,12 +306,48 @@ class Matrix:
             gen_mat = None if logged else Matrix.zero(n, 0)  # :998 vs :888
         return Matrix.AffineSubspace(particular, gen_mat)
 
-    def inverse(self, log_matrices: bool = False, log_steps: bool = False, log_result: bool = False):
-        """linalg.py:682-743: Matrix, or NoSolution() when singular."""
+    def _find_preimage_traced(self, aug: List[List[Any]], n: int, full: bool):
+        """The reference's logging path (linalg.py:655-680): reduction in its own operation order, its exact
+        inconsistency test (:913-934) and extraction (:937-999).  The reference writes the step log to
+        its global LaTeX logger; here it is kept on the object as `last_trace` = (matrices, steps)."""
+        items, pivots, mats, steps = Matrix(aug).row_reduce(bar_col=n, trace=("full" if full else "steps"))
+        self.last_trace = (mats, steps)
+        for row in items:  # :918-934, exact comparisons as in the reference
+            if all(v == 0 for v in row[:n]) and row[n] != 0:
+                return Matrix.NoSolution()
+        col_of_row = {r: c for r, c in pivots}
+        pivot_cols = {c for _, c in pivots}
+        particular: List[Any] = [0] * n
+        for r, c in col_of_row.items():
+            particular[c] = items[r][n]
+        gens = []
+        for fj in [j for j in range(n) if j not in pivot_cols]:
+            g: List[Any] = [0] * n
+            g[fj] = 1
+            for r, c in col_of_row.items():
+                g[c] = -items[r][fj]
+            gens.append(g)
+        gen_mat = Matrix([list(col) for col in zip(*gens)]) if gens else None  # :985, :998
+        return Matrix.AffineSubspace(particular, gen_mat)
+
+    def inverse(self, log_matrices: bool = False, log_steps: bool = False, log_result: bool = False, trace=False):
+        """linalg.py:682-743: Matrix, or NoSolution() when singular.  trace: as in find_preimage_of."""
         if self.rows != self.cols:
             raise ValueError("Matrix must be square to invert.")  # :692-693
         A = _as_array(self.items)
         n = A.shape[0]
+        if trace:
+            # the reference's logging path (:703-743): [A|I] reduced in its own operation order, left block
+            # compared with I to 1e-12, right block returned; the log is kept as `last_trace`
+            ident = Matrix.identity(n).items
+            items, _piv, mats, steps = Matrix([list(self.items[i]) + ident[i] for i in range(n)]).row_reduce(
+                bar_col=n, trace=("steps" if trace == "steps" else "full"))
+            self.last_trace = (mats, steps)
+            for i in range(n):
+                for j in range(n):
+                    if abs(items[i][j] - (1.0 if i == j else 0.0)) > 1e-12:
+                        return Matrix.NoSolution()  # :737
+            return Matrix([row[n:] for row in items])
         X, info, ratio = dense.inv(A)
         if info != 0 or not (ratio > dense.EPS64 * n):
             return Matrix.NoSolution()  # :701 / :737

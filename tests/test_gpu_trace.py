@@ -1,0 +1,122 @@
+"""Traced row reduction on the GPU (lsx_rref_trace_f64): the reference's own operation order with its
+step log.  Everything here is compared BIT FOR BIT with vectors captured from the reference."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from helpers import dec, dec_mat, is_numeric_case, load_big, load_small_cases, same_matrix, same_scalar  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def la():
+    import linalg_solver_amd as la_
+    return la_
+
+
+def _latex_cases():
+    with open(os.path.join(HERE, "golden", "latex_cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+def _bits(M):
+    return [[float(v).hex() for v in row] for row in M]
+
+
+@pytest.mark.parametrize("case", _latex_cases(), ids=[c["name"] for c in _latex_cases()])
+def test_traced_row_reduce_reproduces_the_reference_log(la, case):
+    items = [[float.fromhex(v) for v in row] for row in case["items"]]
+    red, pivots, mats, steps = la.Matrix(items).row_reduce(case["bar_col"], trace=True)
+    assert _bits(red) == case["reduced"]
+    assert [list(p) for p in pivots] == case["pivots"]
+    assert [list(s) for s in steps] == case["steps"]
+    assert mats == case["matrices"]
+    red2, piv2, mats2, steps2 = la.Matrix(items).row_reduce(case["bar_col"], trace="steps")
+    assert _bits(red2) == case["reduced"] and piv2 == pivots and steps2 == steps and mats2 == []
+
+
+RR = [c for c in load_small_cases() if c["op"] == "row_reduce" and is_numeric_case(dec_mat(c["items"]))]
+
+
+@pytest.mark.parametrize("case", RR, ids=[c["name"] for c in RR])
+def test_traced_row_reduce_small_golden(la, case):
+    """All numeric small cases (int and float entries): every entry identical in TYPE and bits (untouched
+    ints stay ints) -- including the reference's float rank artefacts -- pivots
+    and (label, description) steps identical."""
+    items = dec_mat(case["items"])
+    red, pivots, _, steps = la.Matrix(items).row_reduce(case["bar_col"], trace="steps")
+    want = dec_mat(case["reduced"])
+    assert same_matrix(red, want), (red, want)
+    assert [list(p) for p in pivots] == case["pivots"]
+    assert [list(s) for s in steps] == case["steps"]
+
+
+def _same_result(la, got, want) -> bool:
+    """Typed, bit-level comparison of a caller result with the reference's."""
+    if want["kind"] == "NoSolution":
+        return isinstance(got, la.Matrix.NoSolution)
+    if want["kind"] == "AffineSubspace":
+        if not isinstance(got, la.Matrix.AffineSubspace):
+            return False
+        part = [dec(v) for v in want["particular"]]
+        if len(part) != len(got.vec) or not all(same_scalar(a, b) for a, b in zip(got.vec, part)):
+            return False
+        if want["generators"] is None:
+            return got.generators is None
+        return got.generators is not None and same_matrix(got.generators.items, dec_mat(want["generators"]))
+    return isinstance(got, la.Matrix) and same_matrix(got.items, dec_mat(want["items"]))
+
+
+OTHER = [c for c in load_small_cases() if c["op"] in ("find_preimage_of", "inverse")
+         and is_numeric_case(dec_mat(c["items"]))]
+
+
+@pytest.mark.parametrize("case", OTHER, ids=[c["name"] for c in OTHER])
+def test_traced_solve_and_inverse_small_golden(la, case):
+    items = dec_mat(case["items"])
+    M = la.Matrix(items)
+    if case["op"] == "find_preimage_of":
+        got = M.find_preimage_of([dec(v) for v in case["vec"]], log_steps=True, trace="steps")
+    else:
+        got = M.inverse(log_steps=True, trace="steps")
+    assert _same_result(la, got, case["result"]), (got, case["result"])
+    assert isinstance(M.last_trace, tuple) and len(M.last_trace) == 2
+
+
+def test_cfg1_64x64_traced_is_bit_identical(la):
+    z = np.load(os.path.join(HERE, "golden", "cfg1_n64.npz"))
+    A, b = z["A"], z["b"]
+    red, pivots, mats, steps = la.Matrix(np.hstack([A, b[:, None]]).tolist()).row_reduce(trace=True)
+    assert np.array_equal(np.array(red), z["reduced"])
+    assert [list(p) for p in pivots] == z["pivots"].tolist()
+    assert [s[0] for s in steps] == z["labels"].tolist()
+    assert len(mats) == len(steps) + 1 and mats[0].startswith(r"\left(\begin{array}{" + "c" * 64 + "|c}")
+    sol = la.Matrix(A.tolist()).find_preimage_of(b.tolist(), trace="steps")
+    assert np.array_equal(np.array(sol.vec), z["x"]) and sol.generators is None
+    inv = la.Matrix(A.tolist()).inverse(trace="steps")
+    assert np.array_equal(np.array(inv.items), z["inverse"])
+
+
+@pytest.mark.parametrize("name", ["n128_int5", "n128_u11", "n256_u11", "n512_u11"])
+def test_traced_larger_n_is_bit_identical(la, name):
+    A, b, z = load_big(name)
+    red, pivots, _, steps = la.Matrix(np.hstack([A, b[:, None]]).tolist()).row_reduce(trace="steps")
+    assert [s[0] for s in steps] == z["labels"].tolist()
+    assert np.array_equal(np.array(red)[:, -1], z["x"])
+    n = A.shape[0]
+    assert pivots == [(k, k) for k in range(n)]
+
+
+def test_trace_log_overflow_and_arguments(la):
+    from linalg_solver_amd import dense
+    R, piv, recs, touched, snaps, snap_t = dense.rref_trace(np.array([[0.0, 0.0], [0.0, 0.0]]), bar_col=2)
+    assert piv == [] and recs == [] and snaps is None and snap_t is None and not touched.any()
+    assert np.array_equal(R, np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        dense.rref_trace(np.zeros((0, 3)))

@@ -215,7 +215,7 @@ def main():
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         dev.h.set_option("panel_nt", 0)
         dev.h.set_option("gemm_waves", 0)
-        for mode, rt, look, nb, kb in ((1, 4, 2, 128, 1), (1, 4, 0, 128, 1)):
+        for mode, rt, look, nb, kb in ((3, 4, 0, 128, 1), (3, 4, 2, 128, 1), (3, 4, 1, 128, 1), (3, 4, 0, 128, 2), (3, 4, 0, 64, 1), (3, 4, 0, 96, 1), (1, 4, 0, 128, 1)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
@@ -234,6 +234,8 @@ def main():
                 pr = dev.h.prof_read()
                 print(f"getrf n={n} panel={mode} rt={rt} lookahead={look} nb={nb} kblock={kb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
                       + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()), flush=True)
+        dev.h.set_option("kblock", 1); dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 0)
+        dev.h.set_option("nb", 128)
 
 
 if __name__ == "__main__":
