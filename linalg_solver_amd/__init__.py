@@ -5,9 +5,12 @@
 
 Layers: matrix.py (reference-compatible surface) -> dense.py (numpy buffers)
 -> _native.py (ctypes) -> liblsx.so (hand-written HIP for gfx950, csrc/).
+fmt.py renders the reference's LaTeX; random_matrix.py mirrors its rank-constrained builders.
 """
-from . import dense, gen
+from . import dense, fmt, gen
 from ._native import Handle, LsxError, default_handle
 from .matrix import Matrix
+from .random_matrix import RandomMatrixBuilder, gen_matrix_with_rank, gen_regular_matrix, raw_gen_rand_matrix
 
-__all__ = ["Matrix", "Handle", "LsxError", "default_handle", "dense", "gen"]
+__all__ = ["Matrix", "Handle", "LsxError", "default_handle", "dense", "gen", "fmt", "RandomMatrixBuilder",
+           "gen_matrix_with_rank", "gen_regular_matrix", "raw_gen_rand_matrix"]

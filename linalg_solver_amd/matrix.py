@@ -54,7 +54,10 @@ def _as_array(items: List[List[Any]]) -> np.ndarray:
 
 
 class Matrix:
-    items: List[List[Any]]
+    """Mirror of the reference's `Matrix` carrier (linalg.py:11-58).  `items` is the public, mutable
+    list-of-lists of the reference.  A matrix built with `from_numpy` / `from_dlpack` keeps the array
+    and materialises `items` only when somebody asks for it: at N >= 4096 the O(N^2) Python objects cost
+    seconds, the factorisation milliseconds."""
 
     def __init__(self, items: List[List[Any]]):
         # linalg.py:14-32 -- same checks, same messages
@@ -71,7 +74,26 @@ class Matrix:
             if not all(len(row) == row_len for row in items):
                 raise ValueError("All matrix rows must have the same length")
         self._cols = row_len
-        self.items = items
+        self._items = items
+        self._src = None   # array backing (from_numpy); dropped as soon as `items` is handed out
+
+    @property
+    def items(self) -> List[List[Any]]:
+        if self._items is None:
+            self._items = self._src.tolist()
+            self._src = None   # the lists are mutable: from here on they are the only truth
+        return self._items
+
+    @items.setter
+    def items(self, value: List[List[Any]]):
+        self._items = value
+        self._src = None
+
+    def _array(self) -> np.ndarray:
+        """fp64 image of the entries for the device (validated)."""
+        if self._items is None:
+            return np.ascontiguousarray(self._src, dtype=np.float64)
+        return _as_array(self._items)
 
     # ---- container surface ------------------------------------------------
     def __str__(self) -> str:
@@ -82,11 +104,13 @@ class Matrix:
 
     @property
     def rows(self) -> int:
-        return len(self.items)
+        return self._src.shape[0] if self._items is None else len(self._items)
 
     @property
     def cols(self) -> int:
-        return len(self.items[0]) if self.rows else self._cols
+        if self._items is None:
+            return self._src.shape[1]
+        return len(self._items[0]) if self._items else self._cols
 
     def get_row(self, i: int) -> List[Any]:
         return self.items[i]
@@ -112,13 +136,73 @@ class Matrix:
 
     @classmethod
     def from_numpy(cls, a) -> "Matrix":
-        a = np.asarray(a)
-        if a.ndim != 2:
-            raise ValueError("from_numpy needs a 2-D array")
-        return cls(a.tolist())
+        """2-D integer or floating array -> Matrix without creating the list-of-lists (made on first use
+        of `.items`; integer dtypes give int entries, as the reference's examples use)."""
+        a = np.array(a, copy=True, order="C")
+        if a.ndim != 2 or a.shape[0] == 0:
+            raise ValueError("from_numpy needs a non-empty 2-D array")
+        if a.dtype.kind not in "iuf":
+            raise TypeError(f"from_numpy needs an integer or floating array, got dtype {a.dtype}")
+        m = cls.__new__(cls)
+        m._cols = a.shape[1]
+        m._items = None
+        m._src = a
+        return m
+
+    @classmethod
+    def from_dlpack(cls, x) -> "Matrix":
+        """Any DLPack producer (torch tensor on CPU or GPU, numpy, ...) -> Matrix, copied to the host."""
+        if hasattr(x, "detach") and hasattr(x, "cpu"):      # torch: device tensors cannot go through numpy
+            return cls.from_numpy(x.detach().cpu().numpy())
+        return cls.from_numpy(np.from_dlpack(x))
 
     def to_numpy(self) -> np.ndarray:
-        return _as_array(self.items)
+        """fp64 copy of the entries."""
+        return np.array(self._array(), copy=True)
+
+    def __dlpack__(self, stream=None):
+        return self.to_numpy().__dlpack__()
+
+    def __dlpack_device__(self):
+        return self.to_numpy().__dlpack_device__()
+
+    # ---- array-valued twins of the list-valued API (no O(N^2) Python objects) ----------------------
+    def row_reduce_array(self, bar_col: int = None):
+        """row_reduce on arrays: (reduced ndarray, pivots)."""
+        A = self._array()
+        n = A.shape[1]
+        if n == 0:
+            raise IndexError("list index out of range")
+        bar = bar_col or n - 1
+        R, pivots = self._reduce(A, min(bar, n))
+        if bar > n and len(pivots) < A.shape[0]:
+            raise IndexError("list index out of range")
+        return R, pivots
+
+    def solve_array(self, rhs) -> "np.ndarray | Matrix.NoSolution":
+        """Unique solution(s) of self * X = rhs for a square matrix (rhs: vector or matrix) as an ndarray;
+        NoSolution() when the matrix is singular to working precision (use find_preimage_of for the
+        general affine answer)."""
+        A = self._array()
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("solve_array needs a square matrix")
+        B = np.asarray(rhs, dtype=np.float64)
+        vec = B.ndim == 1
+        if B.shape[0] != A.shape[0]:
+            raise ValueError("Matrix dimensions must match")
+        X, info, ratio = dense.solve(A, B.reshape(A.shape[0], -1))
+        if info != 0 or not (ratio > dense.EPS64 * A.shape[0]):
+            return Matrix.NoSolution()
+        return X[:, 0] if vec else X
+
+    def inverse_array(self) -> "np.ndarray | Matrix.NoSolution":
+        A = self._array()
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("Matrix must be square to invert.")
+        X, info, ratio = dense.inv(A)
+        if info != 0 or not (ratio > dense.EPS64 * A.shape[0]):
+            return Matrix.NoSolution()
+        return X
 
     def transpose(self) -> "Matrix":
         return Matrix([[self.items[j][i] for j in range(self.rows)] for i in range(self.cols)])
@@ -135,7 +219,7 @@ class Matrix:
             return self.scalar_mul(other)  # linalg.py:101-103
         if self.cols != other.rows:
             raise ValueError("Matrix dimensions must match")  # linalg.py:104-105
-        return Matrix(dense.matmul(_as_array(self.items), _as_array(other.items)).tolist())
+        return Matrix(dense.matmul(self._array(), other._array()).tolist())
 
     def cformat(self, _arg_of: str = "") -> str:
         body = r"\\".join(" & ".join(_fmt(v) for v in row) for row in self.items)
@@ -219,7 +303,7 @@ class Matrix:
         list is truncated to the first steps.
         Entry types follow the reference's object arithmetic: ints stay ints until a division or a float
         operand touches them (exact up to 2^53)."""
-        A = _as_array(self.items)
+        A = self._array()
         n = A.shape[1]
         if n == 0:
             raise IndexError("list index out of range")  # reference fails at len(A[0]) / A[0][0]
@@ -268,7 +352,7 @@ class Matrix:
         if self.rows != len(vec):
             raise ValueError("Matrix dimensions must match")  # :642-643
         logged = log_matrices or log_steps or log_result
-        A = _as_array(self.items)
+        A = self._array()
         b = _as_array([[v] for v in vec])
         n = A.shape[1]
         if n == 0:
@@ -334,7 +418,7 @@ class Matrix:
         """linalg.py:682-743: Matrix, or NoSolution() when singular.  trace: as in find_preimage_of."""
         if self.rows != self.cols:
             raise ValueError("Matrix must be square to invert.")  # :692-693
-        A = _as_array(self.items)
+        A = self._array()
         n = A.shape[0]
         if trace:
             # the reference's logging path (:703-743): [A|I] reduced in its own operation order, left block
@@ -359,20 +443,24 @@ class Matrix:
             raise ValueError("Determinant requires a square matrix")
         if self.rows == 1:
             return self.items[0][0]  # :200-201
-        return dense.det(_as_array(self.items))
+        return dense.det(self._array())
 
     def slogdet(self) -> Tuple[float, float]:
         """(sign, log|det|): the overflow-free form of determinant() (new API)."""
         if self.rows != self.cols:
             raise ValueError("Determinant requires a square matrix")
-        return dense.slogdet(_as_array(self.items))
+        return dense.slogdet(self._array())
 
     def rank(self) -> int:
         """linalg.py:745-747."""
-        A = _as_array(self.items)
+        A = self._array()
         if A.shape[1] == 0:
             return 0
-        return dense.rref(A, bar_col=A.shape[1])[2]
+        # partial pivoting for the rank decision: the first-non-zero rule is the reference's order of
+        # operations, but its unpivoted growth can lift rounding noise over the tolerance (a 5 x 7 integer
+        # matrix of rank 3 came out as 4)
+        from ._native import PIVOT_MAX
+        return dense.rref(A, bar_col=A.shape[1], pivot_rule=PIVOT_MAX)[2]
 
     def kernel(self) -> "Matrix.AffineSubspace":
         """linalg.py:749-756."""

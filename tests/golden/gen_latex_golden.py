@@ -42,7 +42,15 @@ def main():
     cases.append(case("inverse_shape_bar2", [[2.0, 1.0, 1.0, 0.0], [1.0, 3.0, 0.0, 1.0]], bar_col=2))
     cases.append(case("tiny_and_huge", [[1e-7, 3e15, 1.0], [2.5e-6, 1e16, 7.0]]))
     cases.append(case("single_column", [[2.0], [4.0]]))
-    out = {"generator": "tests/golden/gen_latex_golden.py", "reference": G.REF, "cases": cases}
+    # the reference's rank-constrained builders under fixed seeds (random_matrix.py:109-130, 222-247)
+    import linalg_solver.random_matrix as RM
+    builder = []
+    for seed in (1, 2, 3, 4, 5):
+        random.seed(seed)
+        reg = RM.gen_regular_matrix(6)
+        rk = RM.gen_matrix_with_rank(5, 7, 3)
+        builder.append({"seed": seed, "regular6": reg.items, "rank3_5x7": rk.items})
+    out = {"generator": "tests/golden/gen_latex_golden.py", "reference": G.REF, "cases": cases, "builder": builder}
     with open(os.path.join(HERE, "latex_cases.json"), "w") as f:
         json.dump(out, f, indent=0, ensure_ascii=False)
     print(f"wrote {len(cases)} cases, {sum(len(c['matrices']) for c in cases)} LaTeX matrices")

@@ -120,3 +120,56 @@ def test_trace_log_overflow_and_arguments(la):
     assert np.array_equal(R, np.zeros((2, 2)))
     with pytest.raises(ValueError):
         dense.rref_trace(np.zeros((0, 3)))
+
+
+def _builder_cases():
+    with open(os.path.join(HERE, "golden", "latex_cases.json")) as f:
+        return json.load(f)["builder"]
+
+
+@pytest.mark.parametrize("case", _builder_cases(), ids=[f"seed{c['seed']}" for c in _builder_cases()])
+def test_random_matrix_builders_follow_the_reference_stream(la, case):
+    """random_matrix.py:109-130 with the rank tests and the product on the GPU: same seed, same matrices."""
+    import random
+    random.seed(case["seed"])
+    reg = la.gen_regular_matrix(6)
+    rk = la.gen_matrix_with_rank(5, 7, 3)
+    assert same_matrix(reg.items, case["regular6"])
+    assert same_matrix(rk.items, case["rank3_5x7"])
+    assert reg.rank() == 6 and rk.rank() == 3
+    with pytest.raises(NotImplementedError):
+        la.RandomMatrixBuilder.new().with_eigenvalues([1.0, 2.0])
+
+
+def test_array_backed_matrix_and_dlpack(la):
+    """from_numpy / from_dlpack keep the array (no list-of-lists until `.items` is read); the array-valued
+    twins agree with the list-valued API."""
+    import torch
+    rng = np.random.default_rng(5)
+    A = rng.uniform(-1, 1, (300, 300))
+    b = rng.uniform(-1, 1, 300)
+    M = la.Matrix.from_numpy(A)
+    assert M._items is None and M.rows == 300 and M.cols == 300
+    x = M.solve_array(b)
+    assert M._items is None, "the numeric path must not materialise the Python lists"
+    assert np.max(np.abs(A @ x - b)) < 1e-9
+    inv = M.inverse_array()
+    assert np.max(np.abs(A @ inv - np.eye(300))) < 1e-8
+    R, piv = la.Matrix.from_numpy(np.hstack([A, b[:, None]])).row_reduce_array()
+    assert piv == [(k, k) for k in range(300)] and np.max(np.abs(R[:, -1] - x)) < 1e-9
+    sol = M.find_preimage_of(b.tolist())
+    assert np.max(np.abs(np.array(sol.vec) - x)) < 1e-12
+    assert M.items[0][0] == A[0, 0] and M._src is None          # lists on demand; then they are the truth
+    M.items[0][0] = 2.0
+    assert M.to_numpy()[0, 0] == 2.0
+    T = torch.tensor(A, device="cuda")
+    Md = la.Matrix.from_dlpack(T)
+    assert np.array_equal(Md.to_numpy(), A)
+    Mi = la.Matrix.from_numpy(np.array([[1, 2], [3, 4]]))
+    assert Mi.items == [[1, 2], [3, 4]] and all(isinstance(v, int) for v in Mi.items[0])
+    assert np.array_equal(np.from_dlpack(Mi), np.array([[1.0, 2.0], [3.0, 4.0]]))
+    singular = la.Matrix.from_numpy(np.ones((4, 4)))
+    assert isinstance(singular.inverse_array(), la.Matrix.NoSolution)
+    assert isinstance(singular.solve_array(np.ones(4)), la.Matrix.NoSolution)
+    with pytest.raises(TypeError):
+        la.Matrix.from_numpy(np.array([["a", "b"]]))
