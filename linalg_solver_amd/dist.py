@@ -10,6 +10,11 @@ blocks as one row-major local matrix.  Per block step:
     everyone   applies the interchanges to its other columns, solves its slice of
                U12 with L11, and updates its slice of A22 -= L21 * U12 (MFMA)
 
+Look-ahead (depth 1): the owner of panel b+1 updates that one column block first, factors it and starts
+its broadcast, THEN finishes its share of update b; the other ranks post the receive for panel b+1 before
+they start update b.  The panel factorisation (latency-bound, ~2 us per column) and the broadcast thus run
+under the trailing update instead of in front of it.  Two broadcast buffers alternate.
+
 No reduction is needed: the trailing update is embarrassingly parallel over
 column blocks; the only exchange is the panel broadcast, which the reference has
 no counterpart for (it is single-threaded).
@@ -51,10 +56,11 @@ class ShardedLU:
             self.offset[b] = off
             off += self.widths[b]
         self.local_cols = off
-        # broadcast buffer: [gather list: 512 int32 = 256 T | has-list flag | info | pivots (as T) | panel rows]
-        self._buf = torch.zeros((258 + nb + n * nb,), dtype=dtype, device=self.device)
-        self._moves = self._buf[:256].view(torch.int32)  # raw int32 view of the first 2 KB
+        # broadcast buffers (two, alternating with the block step):
+        # [gather list: 512 int32 = 256 T | has-list flag | info | pivots (as T) | panel rows]
+        self._bufs = [torch.zeros((258 + nb + n * nb,), dtype=dtype, device=self.device) for _ in range(2)]
         self._fast_swaps = hasattr(ops, "panel_moves_") and hasattr(ops, "laswp_moves_")
+        self._custom_bcast = bcast is not None
 
     # -- distribution helpers -------------------------------------------------
     def owner(self, b: int) -> int:
@@ -88,22 +94,51 @@ class ShardedLU:
         dist.all_reduce(full, group=self.group)  # disjoint supports: the sum is the union
         return full
 
-    def _has_list_host(self, buf, own) -> bool:
-        """Whether the broadcast carried a gather list.  The flag is known on the host without a
-        device read: the owner's panel kernel either always or never emits one for a given shape,
-        and every rank runs the same library -- so ask the local ops object once per shape."""
-        key = "list"
-        if not hasattr(self, "_list_cache"):
-            self._list_cache = {}
-        if key not in self._list_cache:
-            self._list_cache[key] = bool(buf[256].item() > 0.5)  # one sync, first step only
-        return self._list_cache[key]
+    def _has_list_host(self, buf) -> bool:
+        """Whether the broadcasts carry a gather list.  The owner's panel kernel either always or never
+        emits one for a given build, and every rank runs the same library -- so read the flag once per
+        factorisation (one sync, first step only)."""
+        if "list" not in self._list_cache:
+            self._list_cache["list"] = bool(buf[256].item() > 0.5)
+        return self._list_cache["list"]
 
     def _first_local_block_after(self, b: int) -> Optional[int]:
         for mb in self.my_blocks:
             if mb > b:
                 return mb
         return None
+
+    # -- the exchange ---------------------------------------------------------
+    def _bcast_start(self, t: torch.Tensor, src: int):
+        """Start the broadcast of one step.  RCCL: asynchronous, returns the work handle (the transfer
+        runs on the collective's own stream beside the update kernels).  A caller-supplied exchange
+        (tests, host staging) is blocking."""
+        if self._custom_bcast:
+            self._bcast(t, src)
+            return None
+        return dist.broadcast(t, src=src, group=self.group, async_op=True)
+
+    @staticmethod
+    def _bcast_wait(work):
+        if work is not None:
+            work.wait()
+
+    def _pack_panel(self, A, b, ipiv, info):
+        """Owner: factor panel b in place and fill its broadcast buffer."""
+        n, nb, ops = self.n, self.nb, self.ops
+        k = b * nb
+        jb = min(nb, n - k)
+        m = n - k
+        buf = self._bufs[b & 1][: 258 + jb + m * jb]
+        o = self.offset[b]
+        P = A[k:, o:o + jb]
+        ops.panel_(P, k, ipiv[k:k + jb], info)
+        buf[258 + jb:].view(m, jb).copy_(P)
+        buf[258:258 + jb].copy_(ipiv[k:k + jb])   # int32 -> T in one copy kernel
+        buf[257:258].copy_(info)
+        has_list = self._fast_swaps and ops.panel_moves_(buf[:256].view(torch.int32))
+        buf[256:257].fill_(1.0 if has_list else 0.0)
+        return buf
 
     # -- the factorisation ------------------------------------------------------
     def factor_(self, A: torch.Tensor):
@@ -114,48 +149,81 @@ class ShardedLU:
         ipiv = torch.zeros(n, dtype=torch.int32, device=self.device)
         info = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._list_cache = {}
-        for b in range(self.nblocks):
+
+        def shape(b):
             k = b * nb
             jb = min(nb, n - k)
-            m = n - k
-            own = self.owner(b)
-            buf = self._buf[: 258 + jb + m * jb]
-            panel = buf[258 + jb:].view(m, jb)
-            if own == self.rank:
-                o = self.offset[b]
-                P = A[k:, o:o + jb]
-                ops.panel_(P, k, ipiv[k:k + jb], info)
-                panel.copy_(P)
-                buf[258:258 + jb].copy_(ipiv[k:k + jb])   # int32 -> T in one copy kernel
-                buf[257:258].copy_(info)
-                has_list = self._fast_swaps and ops.panel_moves_(self._moves)
-                buf[256:257].fill_(1.0 if has_list else 0.0)
-            # the one exchange of the step: factored panel + pivots (+ gather list), owner -> everyone
-            self._bcast(buf, own)
-            if own != self.rank:
-                ipiv[k:k + jb].copy_(buf[258:258 + jb])   # exact: row indices < 2^53
-                info.copy_(buf[257:258])
-            # interchanges on this rank's other columns (the owner's panel is already swapped)
-            piv = ipiv[k:k + jb]
-            use_list = self._fast_swaps and self._has_list_host(buf, own)
+            return k, jb, n - k
 
-            def swap_rows(view):
-                if use_list:
-                    ops.laswp_moves_(view, k, self._moves)
-                else:
-                    ops.laswp_(view, k, jb, piv)
-            nxt = self._first_local_block_after(b)
-            left_cols = self.offset[b] if own == self.rank else (self.offset[nxt] if nxt is not None
-                                                                  else self.local_cols)
-            if left_cols > 0:
-                swap_rows(A[:, :left_cols])
-            if nxt is not None:
-                ro = self.offset[nxt]
-                right = A[:, ro:self.local_cols]
-                swap_rows(right)
-                # U12 slice and trailing update of this rank's columns right of the panel
-                U12 = A[k:k + jb, ro:self.local_cols]
-                ops.trsm_lu_(panel[:jb, :], U12)
-                if m > jb:
-                    ops.gemm_sub_(A[k + jb:, ro:self.local_cols], panel[jb:, :], U12)
+        def buf_of(b):
+            k, jb, m = shape(b)
+            return self._bufs[b & 1][: 258 + jb + m * jb]
+
+        def unpack(b):
+            """Non-owner: pivots and info of panel b out of its buffer."""
+            k, jb, m = shape(b)
+            buf = buf_of(b)
+            ipiv[k:k + jb].copy_(buf[258:258 + jb])   # exact: row indices < 2^53
+            info.copy_(buf[257:258])
+
+        def apply_panel(b, col0, col1):
+            """Interchanges, U12 and trailing update of local columns [col0, col1) with panel b."""
+            if col1 <= col0:
+                return
+            k, jb, m = shape(b)
+            buf = buf_of(b)
+            panel = buf[258 + jb:].view(m, jb)
+            view = A[:, col0:col1]
+            if self._fast_swaps and self._has_list_host(buf):
+                ops.laswp_moves_(view, k, buf[:256].view(torch.int32))
+            else:
+                ops.laswp_(view, k, jb, ipiv[k:k + jb])
+            U12 = A[k:k + jb, col0:col1]
+            ops.trsm_lu_(panel[:jb, :], U12)
+            if m > jb:
+                ops.gemm_sub_(A[k + jb:, col0:col1], panel[jb:, :], U12)
+
+        def swap_left(b, ncols):
+            if ncols <= 0:
+                return
+            k, jb, m = shape(b)
+            buf = buf_of(b)
+            if self._fast_swaps and self._has_list_host(buf):
+                ops.laswp_moves_(A[:, :ncols], k, buf[:256].view(torch.int32))
+            else:
+                ops.laswp_(A[:, :ncols], k, jb, ipiv[k:k + jb])
+
+        # panel 0: factored and sent before the loop
+        own0 = self.owner(0)
+        if own0 == self.rank:
+            self._pack_panel(A, 0, ipiv, info)
+        self._bcast_wait(self._bcast_start(buf_of(0), own0))
+        if own0 != self.rank:
+            unpack(0)
+
+        for b in range(self.nblocks):
+            own = self.owner(b)
+            has_next = b + 1 < self.nblocks
+            own_next = self.owner(b + 1) if has_next else -1
+            nxt = self._first_local_block_after(b)       # first local block right of panel b
+            right0 = self.offset[nxt] if nxt is not None else self.local_cols
+            work = None
+            if has_next and own_next == self.rank:
+                # look-ahead: bring block b+1 up to date, factor it, start its broadcast ...
+                assert nxt == b + 1
+                w = self.widths[nxt]
+                apply_panel(b, right0, right0 + w)
+                self._pack_panel(A, b + 1, ipiv, info)
+                work = self._bcast_start(buf_of(b + 1), own_next)
+                right0 += w                                # ... then the rest of update b
+            elif has_next:
+                work = self._bcast_start(buf_of(b + 1), own_next)   # receive posted before the update
+            apply_panel(b, right0, self.local_cols)
+            # interchanges on the columns left of the panel (the owner's panel is already swapped)
+            swap_left(b, self.offset[b] if own == self.rank else (self.offset[nxt] if nxt is not None
+                                                                  else self.local_cols))
+            if has_next:
+                self._bcast_wait(work)
+                if own_next != self.rank:
+                    unpack(b + 1)
         return ipiv, info
