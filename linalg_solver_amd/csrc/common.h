@@ -169,8 +169,6 @@ int launch_gather_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_perm, 
 template <typename T>
 int launch_set_identity_perm(lsx_handle_t h, int n, const int32_t *d_perm, T *X, int ldx);
 template <typename T>
-int launch_apply_ipiv_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_ipiv, T *B, int ldb);
-template <typename T>
 int launch_det(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, double *d_out);
 template <typename T>
 int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots,

@@ -466,33 +466,6 @@ int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm,
 }
 
 // ------------------------------------------------------------------ permutation helpers
-// Apply all n interchanges of a factorisation to the rows of B (n x ncols):
-// forward order, as LAPACK's laswp.  One thread per column walks the list;
-// rows it touches are L2-resident for the narrow right-hand sides this serves.
-template <typename T>
-__global__ void apply_ipiv_rows_kernel(int n, int ncols, const int32_t *__restrict__ ipiv, T *B,
-                                       int ldb) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncols) return;
-    for (int k = 0; k < n; ++k) {
-        const int p = ipiv[k];
-        if (p != k) {
-            const T a = B[(size_t)k * ldb + c], b = B[(size_t)p * ldb + c];
-            B[(size_t)k * ldb + c] = b;
-            B[(size_t)p * ldb + c] = a;
-        }
-    }
-}
-
-template <typename T>
-int launch_apply_ipiv_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_ipiv, T *B, int ldb) {
-    if (n <= 0 || ncols <= 0) return LSX_OK;
-    ProfScope ps(h, LSX_PROF_OTHER);
-    hipLaunchKernelGGL(apply_ipiv_rows_kernel<T>, dim3((ncols + 63) / 64), dim3(64), 0, h->stream, n,
-                       ncols, d_ipiv, B, ldb);
-    LSX_HIP(hipGetLastError());
-    return LSX_OK;
-}
 
 // perm[i] = original row that ends at position i after all n interchanges.
 // Each thread walks the interchange list backwards from its own position
@@ -709,7 +682,6 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
                                       int);                                                       \
-    template int launch_apply_ipiv_rows<T>(lsx_handle_t, int, int, const int32_t *, T *, int);    \
     template int launch_set_identity_perm<T>(lsx_handle_t, int, const int32_t *, T *, int);       \
     template int launch_det<T>(lsx_handle_t, int, const T *, int, const int32_t *, double *);     \
     template int launch_copy2d<T>(lsx_handle_t, int, int, const T *, int, T *, int);              \

@@ -18,12 +18,6 @@ namespace lsx {
 
 constexpr int PROWS = 32;  // rows per workgroup in panel_update
 
-template <typename T>
-struct Cand {
-    T val;     // |a|
-    int idx;   // local row
-};
-
 // wave-level arg-max on (|v|, lowest row wins ties)
 template <typename T>
 __device__ __forceinline__ void wave_argmax(T &v, int &i) {
