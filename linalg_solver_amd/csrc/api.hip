@@ -191,10 +191,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         T *A12 = A + (size_t)k * lda + k + jb;
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
-        LSX_TRY(apply_panel_swaps<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
-        LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
-        LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Tinv, A12, lda));
+        // the chain panel k -> panel k+1 is the critical path: only the next panel's own column block
+        // goes through interchanges / U12 / update before the side stream is released; the other columns
+        // follow while the panel runs
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
+        LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
+        LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
+        LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Tinv, A12, lda));
         LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
         LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
@@ -205,8 +208,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
             LSX_HIP(hipEventRecord(h->ev_panel, side));
         }
         const bool next_valid = h->moves_valid;
-        if (rest > jb2)
+        if (rest > jb2) {
+            h->moves = h->moves_buf[step & 1];   // panel k's list again (the launch above switched it)
+            h->moves_valid = mv_valid;
+            LSX_TRY(apply_panel_swaps<T>(h, rest - jb2, A + k + jb + jb2, lda, k, jb, d_ipiv + k));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest - jb2, Akk, lda, Tinv, A12 + jb2, lda));
             LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
+        }
         // panel k's interchanges on the columns left of it, from panel k's own list
         h->moves = h->moves_buf[step & 1];
         h->moves_valid = mv_valid;
