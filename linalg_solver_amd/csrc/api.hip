@@ -324,6 +324,7 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
         const size_t vec = pad256(sizeof(T) * (size_t)n * nr);
         LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n) + 3 * vec));
         LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * b64 + 2 * b128));
+        LSX_TRY(ensure_scratch(h, 512 + 2 * (size_t)((n + 127) / 128) * 128 * nr * 16));  // the solve's exchange area
         int32_t *perm = (int32_t *)h->ws3;
         T *Bc = (T *)((char *)h->ws3 + pad256(sizeof(int32_t) * n));  // copy of B, zero-padded to nr columns
         T *Bp = (T *)((char *)Bc + vec);                               // P * B, work space of the solve
@@ -581,6 +582,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value >= 0 && value <= 3);
         h->panel_mode = value;
+    } else if (!strcmp(key, "trsv")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->trsv_mode = value;
     } else if (!strcmp(key, "gemm_stagger")) {
         LSX_ARG(value >= 0 && value <= 64);
         h->gemm_stagger = value;
@@ -617,6 +621,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "kblock")) *value = h->kblock;
     else if (!strcmp(key, "gemm_waves")) *value = h->gemm_waves;
     else if (!strcmp(key, "gemm_stagger")) *value = h->gemm_stagger;
+    else if (!strcmp(key, "trsv")) *value = h->trsv_mode;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }

@@ -70,6 +70,7 @@ struct lsx_handle_s {
     int lookahead = 0;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets (+9 % at n~8192, bit-identical)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
+    int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step
     int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)

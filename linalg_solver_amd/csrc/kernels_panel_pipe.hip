@@ -41,16 +41,6 @@ __device__ __forceinline__ float readlane_t(float v, int l) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
 }
 
-// Polling loads must be re-issued on every trip of a spin loop.  hipcc hoists a plain buffer load out
-// of a loop without stores (also with the "volatile" cache-policy bit), and an
-// `asm volatile("" ::: "memory")` fence keeps it in place only at the price of a full vmcnt(0) drain
-// right behind the load, which serialises every shot.  An opaque zero as the scalar offset does it
-// for free: the address looks different on every trip, and the waits stay exact.
-__device__ __forceinline__ int opaque_zero() {
-    int z = 0;
-    asm volatile("" : "+s"(z));
-    return z;
-}
 constexpr int XLOAD = 16;  // sc1: device scope
 constexpr int PP_STAGGER = 4;  // s_sleep units (64 clk) between the two shots at a block start
 

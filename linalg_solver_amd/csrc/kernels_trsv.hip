@@ -9,6 +9,7 @@
 //              tile; the workgroup that owns the NEXT block then forms x_next = inv(T_next) * b_next
 //              at once, so a step costs one launch, and the factors stream through HBM exactly once.
 #include "common.h"
+#include "panel_xchg.h"
 
 namespace lsx {
 
@@ -162,6 +163,202 @@ __global__ __launch_bounds__(256) void trsv_step_kernel(int lower, int n, const 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same solve in ONE launch per direction (option "trsv" = 1, default).  Workgroup w owns rows
+// [64 w, 64 w + 64) for the whole sweep and keeps their right-hand sides on chip; all workgroups are
+// co-resident (n <= 64 * #CUs).  Per 64-row step k the only cross-CU traffic is x_k: its owner forms
+// it from its finished rows with the 64 x 64 diagonal-block inverse and publishes it as
+// self-validating 16-byte granules {value, tag} (write-through stores, no flag, no drain); every
+// workgroup still below (above, for the upper solve) polls the 64 granules and updates its rows from a
+// factor block it loaded into registers before the poll.  One hop per step, no redundant work, the
+// factors stream through HBM exactly once, every spin is bounded.
+constexpr int CB = 64;   // rows per workgroup = step width of the cooperative solve
+
+// sum over the 4 adjacent lanes of a quad by DPP (VALU rate; __shfl_xor goes through the LDS crossbar,
+// ~100 cycles per dependent step, which at 8 right-hand sides was most of a solve step)
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_d<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_d<0x4E>(v);   // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(dpp_i<0xB1>(__float_as_int(v)));
+    v += __int_as_float(dpp_i<0x4E>(__float_as_int(v)));
+    return v;
+}
+
+template <typename T, int NR, bool LOWER>
+__global__ __launch_bounds__(256) void trsv_coop_kernel(int n, const T *__restrict__ LU, int lda,
+                                                        const T *__restrict__ inv64, const T *__restrict__ Bin,
+                                                        int ldb, T *__restrict__ X, XGran *xb, int *status) {
+    constexpr int LSD = CB + 2;            // LDS row stride of a staged factor block
+    constexpr int NF = (CB * CB + 191) / 192;   // factor entries per loader thread (waves 1-3)
+    __shared__ __attribute__((aligned(16))) T Ls[3][CB][LSD];   // factor blocks of steps i, i+1, i+2
+    // x_k and the own right-hand sides: row r, column q at XI(r, q).  The four 16-row groups (one per
+    // `part`) are 16 bytes out of step so that the four addresses of one broadcast read fall into
+    // different banks (a plain [64][NR] layout puts them 1 KB apart at NR = 8: a 4-way conflict on
+    // every read, which made a step three times longer at 8 right-hand sides)
+    constexpr int XG = 16 * NR + 2;
+    __shared__ T xk[4 * XG];
+    __shared__ T bown[4 * XG];
+    auto XI = [](const int r, const int q) __attribute__((always_inline)) { return (r >> 4) * XG + (r & 15) * NR + q; };
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, w = blockIdx.x;
+    const int r0 = w * CB;
+    const int nblk = (n + CB - 1) / CB;
+    const int row_l = tid >> 2, part = tid & 3;   // 4 threads per row, 16 columns of the block each
+    const int row = r0 + row_l;
+    __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(xb, 0, nblk * CB * NR * (int)sizeof(XGran), 0x00020000);
+    if (tid == 0) s_fail = 0;
+    for (int e = tid; e < CB * NR; e += 256) {
+        const int r = e / NR, q = e % NR;
+        bown[XI(r, q)] = (r0 + r < n) ? Bin[(size_t)(r0 + r) * ldb + q] : T(0);
+    }
+    // this thread's 16 entries of its own row of inv(T_ww), used once at the end
+    T dv[16];
+    {
+        const T *inv = inv64 + (size_t)w * CB * CB + (size_t)row_l * CB + 16 * part;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) dv[c] = inv[c];
+    }
+    // Wave 0 only polls: vector-memory returns come back in issue order, so a poll queued behind
+    // HBM loads would wait for them.  Waves 1-3 stream the factor blocks two steps ahead: global ->
+    // registers at the top of a step, registers -> LDS at its end.
+    const int k_first = LOWER ? 0 : nblk - 1;
+    const int dk = LOWER ? 1 : -1;
+    const int cnt = LOWER ? w : nblk - 1 - w;   // steps before my own
+    T fr[NF];
+    auto fetch = [&](const int i) __attribute__((always_inline)) {       // step index -> registers
+        const int k = k_first + i * dk;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int e = (tid - 64) + 192 * j;
+            const int r = e / CB, c = e % CB;
+            const int gr = r0 + r, gc = k * CB + c;
+            fr[j] = (e < CB * CB && gr < n && gc < n) ? LU[(size_t)gr * lda + gc] : T(0);
+        }
+    };
+    auto stash = [&](const int i) __attribute__((always_inline)) {       // registers -> LDS buffer of step i
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int e = (tid - 64) + 192 * j;
+            if (e < CB * CB) Ls[i % 3][e / CB][e % CB] = fr[j];
+        }
+    };
+    if (tid >= 64) {
+        if (cnt > 0) { fetch(0); stash(0); }
+        if (cnt > 1) { fetch(1); stash(1); }
+    }
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) {
+        const int k = k_first + i * dk;
+        if (tid >= 64) {
+            if (i + 2 < cnt) fetch(i + 2);
+        } else {
+            // ---- x_k: CB x NR granules, wave 0: lane r takes row r, all its NR granules per shot
+            const int gr = k * CB + tid;
+            T val[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) val[q] = T(0);
+            if (gr < n) {
+                int spins = 0;
+                for (;;) {
+                    u4 g[NR];
+                    const int oz = opaque_zero();
+#pragma unroll
+                    for (int q = 0; q < NR; ++q)
+                        g[q] = __builtin_amdgcn_raw_buffer_load_b128(r_x, (gr * NR + q) * (int)sizeof(XGran), oz, 16);
+                    bool ok = true;
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) ok &= g[q].z == 1u;
+                    if (ok) {
+#pragma unroll
+                        for (int q = 0; q < NR; ++q) {
+                            if (sizeof(T) == 8)
+                                val[q] = (T)__longlong_as_double((long long)(((unsigned long long)g[q].y << 32) | g[q].x));
+                            else
+                                val[q] = (T)__uint_as_float(g[q].x);
+                        }
+                        break;
+                    }
+                    if (s_fail || ++spins > (1 << 20)) { s_fail = 1; break; }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) xk[XI(tid, q)] = val[q];
+        }
+        __syncthreads();
+        // ---- own rows: b_row -= T[row, block k] * x_k
+        {
+            const T *lrow = &Ls[i % 3][row_l][16 * part];
+            T acc[NR];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[q] = T(0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const T l = lrow[c];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) acc[q] += l * xk[part * XG + c * NR + q];
+            }
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[q] = quad_sum(acc[q]);
+            if (part == 0) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) bown[XI(row_l, q)] -= acc[q];
+            }
+        }
+        if (tid >= 64 && i + 2 < cnt) stash(i + 2);   // buffer (i+2)%3 was last read in step i-1
+        __syncthreads();
+    }
+    // ---- my rows are final: x_w = inv(T_ww) b_w, published and stored
+    {
+        T acc[NR];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] = T(0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int q = 0; q < NR; ++q) acc[q] += dv[c] * bown[part * XG + c * NR + q];
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] = quad_sum(acc[q]);
+        if (part == 0 && row < n) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                unsigned long long bits;
+                if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)acc[q]);
+                else bits = (unsigned long long)__float_as_uint((float)acc[q]);
+                u4 v;
+                v.x = (unsigned)bits; v.y = (unsigned)(bits >> 32); v.z = 1u; v.w = 0u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, r_x, (row * NR + q) * (int)sizeof(XGran), 0, 16);
+                X[(size_t)row * NR + q] = acc[q];
+            }
+        }
+    }
+    if (s_fail && tid == 0) atomicExch(status, 1);
+}
+
+// cooperative variant: true when it ran
+template <typename T, int NR>
+static int trsv_coop_run(lsx_handle_t h, int n, const T *LU, int lda, T *B, int ldb, T *X, const T *inv64L,
+                         const T *inv64U) {
+    const int wgs = (n + CB - 1) / CB;
+    {
+        // one launch per direction; exchange area (zeroed) + status word in the scratch
+        const size_t xbytes = (size_t)wgs * CB * NR * sizeof(XGran);
+        if (256 + 2 * xbytes > h->scratch_bytes) { set_error("trsv: scratch too small"); return LSX_ERR_INTERNAL; }
+        int *status = (int *)h->scratch;
+        XGran *xb0 = (XGran *)((char *)h->scratch + 256), *xb1 = (XGran *)((char *)h->scratch + 256 + xbytes);
+        LSX_HIP(hipMemsetAsync(h->scratch, 0, 256 + 2 * xbytes, h->stream));
+        hipLaunchKernelGGL((trsv_coop_kernel<T, NR, true>), dim3(wgs), dim3(256), 0, h->stream, n, LU, lda, inv64L,
+                           (const T *)B, ldb, X, xb0, status);
+        LSX_TRY(launch_copy2d<T>(h, n, NR, X, NR, B, ldb));  // y is the right-hand side of U x = y
+        hipLaunchKernelGGL((trsv_coop_kernel<T, NR, false>), dim3(wgs), dim3(256), 0, h->stream, n, LU, lda, inv64U,
+                           (const T *)B, ldb, X, xb1, status);
+        LSX_HIP(hipGetLastError());
+        return LSX_OK;
+    }
+}
+
 template <typename T, int NR>
 static int trsv_run(lsx_handle_t h, int n, const T *LU, int lda, T *B, int ldb, T *X, const T *inv128L,
                     const T *inv128U) {
@@ -194,6 +391,16 @@ int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B
     LSX_HIP(hipFuncSetAttribute((const void *)merge128_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m));
     LSX_TRY(launch_trtri<T>(h, 1, n, LU, lda, inv64L));
     LSX_TRY(launch_trtri<T>(h, 0, n, LU, lda, inv64U));
+    // every workgroup must be resident at once; at 8 right-hand sides and large n the per-step path is
+    // as fast (the LDS traffic of the 8-wide update dominates either way)
+    if (h->trsv_mode == 1 && (n + CB - 1) / CB <= h->num_cu && (nrhs <= 4 || n <= 6144)) {
+        switch (nrhs) {
+            case 1: return trsv_coop_run<T, 1>(h, n, LU, lda, B, ldb, X, inv64L, inv64U);
+            case 2: return trsv_coop_run<T, 2>(h, n, LU, lda, B, ldb, X, inv64L, inv64U);
+            case 4: return trsv_coop_run<T, 4>(h, n, LU, lda, B, ldb, X, inv64L, inv64U);
+            case 8: return trsv_coop_run<T, 8>(h, n, LU, lda, B, ldb, X, inv64L, inv64U);
+        }
+    }
     hipLaunchKernelGGL(merge128_kernel<T>, dim3(nblk), dim3(256), shm_m, h->stream, 1, n, LU, lda, inv64L, inv128L);
     hipLaunchKernelGGL(merge128_kernel<T>, dim3(nblk), dim3(256), shm_m, h->stream, 0, n, LU, lda, inv64U, inv128U);
     switch (nrhs) {

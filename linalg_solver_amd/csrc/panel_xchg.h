@@ -1,6 +1,6 @@
 // Shared pieces of the one-launch panel kernels: the cross-CU exchange record formats and the
-// cross-lane (DPP / readlane) reductions.  Included by kernels_panel_coop.hip and
-// kernels_panel_pipe.hip only.
+// cross-lane (DPP / readlane) reductions.  Included by kernels_panel_coop.hip,
+// kernels_panel_pipe.hip and kernels_trsv.hip.
 #pragma once
 #include "common.h"
 
@@ -17,6 +17,17 @@ struct __attribute__((aligned(16))) XGran {
     unsigned epoch;
     unsigned pad;
 };
+
+// Polling loads must be re-issued on every trip of a spin loop.  hipcc hoists a plain buffer load out
+// of a loop without stores (also with the "volatile" cache-policy bit), and an
+// `asm volatile("" ::: "memory")` fence keeps it in place only at the price of a full vmcnt(0) drain
+// right behind the load.  An opaque zero as the scalar offset does it for free: the address looks
+// different on every trip, and the waits stay exact.
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
 
 // ---- DPP cross-lane moves: VALU-rate, no trip through the LDS crossbar (ds_bpermute costs ~100+
 // cycles per dependent step).  Applied in the order quad xor 1, quad xor 2, row_half_mirror,

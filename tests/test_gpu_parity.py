@@ -612,3 +612,29 @@ def test_full_size_fp32(dev):
     res = float(torch.linalg.norm(D) / torch.linalg.norm(A.double()))
     assert res < TOL32, res
     assert float(D.abs().max() / A.abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("n", [129, 200, 1000, 2500])
+@pytest.mark.parametrize("nrhs", [1, 2, 3, 8])
+def test_cooperative_triangular_solve_matches_the_step_path(la, n, nrhs):
+    """Few right-hand sides: one cooperative launch per direction (option trsv=1, default) against one
+    launch per 128-row step (trsv=0) and against the CPU twin."""
+    from linalg_solver_amd import dense, gen
+
+    A, _ = gen.system(gen.U11, 900 + n, n)
+    rng = np.random.default_rng(n + nrhs)
+    B = rng.uniform(-1, 1, (n, nrhs))
+    h = la.default_handle()
+    LU, ipiv, info = dense.lu_factor(A)
+    assert info == 0
+    try:
+        h.set_option("trsv", 0)
+        x0 = dense.lu_solve(LU, ipiv, B)
+        h.set_option("trsv", 1)
+        x1 = dense.lu_solve(LU, ipiv, B)
+    finally:
+        h.set_option("trsv", 1)
+    oLU, oipiv, _ = capi.getrf(A)
+    xo = capi.getrs(oLU, oipiv, B)
+    assert relerr(x1, x0) < 1e-11 and relerr(x1, xo) < TOL64
+    assert np.max(np.abs(A @ x1 - B)) < 1e-9 * n
