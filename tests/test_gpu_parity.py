@@ -638,3 +638,26 @@ def test_cooperative_triangular_solve_matches_the_step_path(la, n, nrhs):
     xo = capi.getrs(oLU, oipiv, B)
     assert relerr(x1, x0) < 1e-11 and relerr(x1, xo) < TOL64
     assert np.max(np.abs(A @ x1 - B)) < 1e-9 * n
+
+
+@pytest.mark.parametrize("n,nrhs", [(300, 1), (1000, 4), (2048, 1)])
+def test_cooperative_triangular_solve_fp32(la, n, nrhs):
+    from linalg_solver_amd import dense, gen
+
+    A, _ = gen.system(gen.U11, 950 + n, n)
+    rng = np.random.default_rng(n)
+    B = rng.uniform(-1, 1, (n, nrhs))
+    LU, ipiv, info = dense.lu_factor(A.astype(np.float32), dtype=np.float32)
+    assert info == 0
+    h = la.default_handle()
+    try:
+        h.set_option("trsv", 0)
+        x0 = dense.lu_solve(LU, ipiv, B.astype(np.float32))
+        h.set_option("trsv", 1)
+        x1 = dense.lu_solve(LU, ipiv, B.astype(np.float32))
+    finally:
+        h.set_option("trsv", 1)
+    assert x1.dtype == np.float32 and relerr(x1.astype(np.float64), x0.astype(np.float64)) < 1e-4
+    # norm-wise backward error of the fp32 solve
+    resid = np.linalg.norm(A @ x1.astype(np.float64) - B) / (np.linalg.norm(A) * np.linalg.norm(x1) + np.linalg.norm(B))
+    assert resid < 1e-4
