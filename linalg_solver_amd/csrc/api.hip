@@ -342,6 +342,7 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
     LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n) + pad256(sizeof(T) * (size_t)n * nrhs)));
     int32_t *perm = (int32_t *)h->ws3;
     T *Bc = (T *)((char *)h->ws3 + pad256(sizeof(int32_t) * n));
+    LSX_TRY(ensure_scratch(h, 8 * (size_t)n + 256));   // index arrays of the permutation conversion
     LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
     LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nrhs));
     LSX_TRY(launch_gather_rows<T>(h, n, nrhs, perm, Bc, nrhs, B, ldb));
@@ -355,6 +356,7 @@ static int getri_dev(lsx_handle_t h, int n, const T *LU, int lda, const int32_t 
     if (n == 0) return LSX_OK;
     LSX_TRY(grow(&h->ws3, &h->ws3_bytes, pad256(sizeof(int32_t) * n)));
     int32_t *perm = (int32_t *)h->ws3;
+    LSX_TRY(ensure_scratch(h, 8 * (size_t)n + 256));
     LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
     LSX_TRY(launch_set_identity_perm<T>(h, n, perm, Inv, ldi));  // P * I
     return lu_solve_permuted<T>(h, n, n, LU, lda, Inv, ldi);

@@ -159,6 +159,8 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
 // unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.
 template <typename T>
 int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv);
+template <typename T>
+int launch_trtri_both(lsx_handle_t h, int n, const T *LU, int lda, T *invL, T *invU);
 // B (jb x ncols) <- inv(Tm) * B in place; Tinv = inverses of Tm's 64x64 diagonal blocks.
 template <typename T>
 int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm, int ldt,

@@ -206,11 +206,17 @@ __device__ void lds_gemm_tile(int M, int N, int K, const T *A, int lda, const T 
     }
 }
 
+// lower = 0 / 1: that triangle; lower = 2: blockIdx.y = 0 inverts the lower, 1 the upper triangle, the
+// upper inverses going to Tinv + upper_off (both triangles of an LU in one launch)
 template <typename T>
 __global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T *__restrict__ Tm,
-                                                      int ldt, T *__restrict__ Tinv) {
+                                                      int ldt, T *__restrict__ Tinv, size_t upper_off) {
     __shared__ T X[TB * TLD];   // triangle in, inverse out
     __shared__ T W[32 * TLD];   // merge temporary
+    if (lower == 2) {
+        lower = blockIdx.y == 0;
+        if (!lower) Tinv += upper_off;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * TB;
     // load (identity outside the matrix / outside the triangle)
@@ -286,7 +292,18 @@ int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tin
     if (jb <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_TRSM);
     hipLaunchKernelGGL(trtri64_kernel<T>, dim3((jb + TB - 1) / TB), dim3(256), 0, h->stream, lower,
-                       jb, Tm, ldt, Tinv);
+                       jb, Tm, ldt, Tinv, (size_t)0);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// inverses of the 64 x 64 diagonal blocks of BOTH triangles of an LU factor, one launch
+template <typename T>
+int launch_trtri_both(lsx_handle_t h, int n, const T *LU, int lda, T *invL, T *invU) {
+    if (n <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_TRSM);
+    hipLaunchKernelGGL(trtri64_kernel<T>, dim3((n + TB - 1) / TB, 2), dim3(256), 0, h->stream, 2, n, LU, lda, invL,
+                       (size_t)(invU - invL));
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -468,22 +485,47 @@ int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm,
 // ------------------------------------------------------------------ permutation helpers
 
 // perm[i] = original row that ends at position i after all n interchanges.
-// Each thread walks the interchange list backwards from its own position
-// (the list is broadcast from LDS / L2), so the conversion is O(n) deep and
-// n-wide instead of an n-step serial chain.
+// Each thread walks the interchange list backwards from its own position (the list is staged in LDS),
+// so the conversion is O(n) deep and n-wide instead of an n-step serial chain.  Two facts keep it
+// short: an interchange (t, p) has p >= t, so it cannot touch a walker whose position is below t --
+// position i starts at step t = i, not n-1; four steps share one 16-byte LDS read; and a group of four
+// that touches no lane of the wave costs five independent compares instead of an 8-deep select chain.  (At n = 4096 a
+// plain full-length walk took 236 us: more than half of a one-right-hand-side solve.)
 __global__ __launch_bounds__(256) void ipiv_to_perm_kernel(int n, const int32_t *__restrict__ ipiv,
                                                            int32_t *__restrict__ perm) {
-    __shared__ int s_piv[2048];
+    __shared__ __attribute__((aligned(16))) int s_piv[2048];
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const int imax = min(n - 1, (int)blockIdx.x * 256 + 255);   // highest position walked by this workgroup
     int x = i;
-    for (int base = ((n - 1) / 2048) * 2048; base >= 0; base -= 2048) {
+    for (int base = (imax / 2048) * 2048; base >= 0; base -= 2048) {
         const int cnt = min(2048, n - base);
         __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += 256) s_piv[k] = ipiv[base + k];
+        // beyond the list: identity interchanges (t, t), which leave every walker where it is
+        for (int k = threadIdx.x; k < 2048; k += 256) s_piv[k] = (k < cnt) ? ipiv[base + k] : base + k;
         __syncthreads();
-        for (int k = cnt - 1; k >= 0; --k) {
-            const int t = base + k, p = s_piv[k];
-            x = (x == t) ? p : ((x == p) ? t : x);
+        // eight steps per trip, the next trip's two 16-byte LDS reads already in flight
+        const int top = min(2047, imax - base) | 7;
+        int4 pa = *(const int4 *)&s_piv[top - 3], pb = *(const int4 *)&s_piv[top - 7];
+        for (int k = top; k >= 7; k -= 8) {
+            const int4 qa = pa, qb = pb;
+            if (k >= 15) {
+                pa = *(const int4 *)&s_piv[k - 11];
+                pb = *(const int4 *)&s_piv[k - 15];
+            }
+            const int t = base + k;
+            // the eight interchanges touch a walker only if it sits on one of their 16 rows: test that
+            // with independent compares and skip the dependent chain when no lane of the wave is hit
+            const bool hit = ((unsigned)(x - (t - 7)) < 8u) | (x == qa.w) | (x == qa.z) | (x == qa.y) | (x == qa.x) |
+                             (x == qb.w) | (x == qb.z) | (x == qb.y) | (x == qb.x);
+            if (!__any(hit)) continue;
+            x = (x == t) ? qa.w : ((x == qa.w) ? t : x);
+            x = (x == t - 1) ? qa.z : ((x == qa.z) ? t - 1 : x);
+            x = (x == t - 2) ? qa.y : ((x == qa.y) ? t - 2 : x);
+            x = (x == t - 3) ? qa.x : ((x == qa.x) ? t - 3 : x);
+            x = (x == t - 4) ? qb.w : ((x == qb.w) ? t - 4 : x);
+            x = (x == t - 5) ? qb.z : ((x == qb.z) ? t - 5 : x);
+            x = (x == t - 6) ? qb.y : ((x == qb.y) ? t - 6 : x);
+            x = (x == t - 7) ? qb.x : ((x == qb.x) ? t - 7 : x);
         }
     }
     if (i < n) perm[i] = x;
@@ -498,10 +540,90 @@ __global__ void gather_rows_kernel(int n, int ncols, const int32_t *__restrict__
     if (j < ncols) D[(size_t)i * ldd + j] = S[(size_t)perm[i] * lds + j];
 }
 
+// The same conversion without an O(n)-deep dependent chain.  Forward view: at step k the rows at
+// positions k and p_k = ipiv[k] >= k swap; position k is final afterwards, so
+//     perm[k] = content of position p_k just before step k,
+// and the content of a position v just before step `bound` is the content position c had just before
+// step c, where c is the LAST step < bound that targeted v (p_c == v) -- or row v itself if no step did.
+// Two index arrays make every hop O(1) apart from skipping later steps that target the same position:
+//     last_target[v] = largest c with p_c == v,       prev_same[c] = largest c' < c with p_c' == p_c.
+// Building them is one pass of independent compares per entry (no loop-carried select chain across
+// 16 dependent operations as in the walk above); the chase itself takes a few hops per row.
+__global__ __launch_bounds__(256) void perm_index_kernel(int n, const int32_t *__restrict__ ipiv,
+                                                         int32_t *__restrict__ last_target,
+                                                         int32_t *__restrict__ prev_same) {
+    __shared__ __attribute__((aligned(16))) int s_piv[2048];
+    // four lanes per entry, each scanning every fourth 16-entry group; the quad's maximum is the answer
+    const int idx = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const bool want_last = blockIdx.y == 0;     // y = 0: last_target[idx], y = 1: prev_same[idx]
+    const int imax = min(n - 1, (int)blockIdx.x * 64 + 63);
+    const int key = want_last ? idx : ((idx < n) ? ipiv[idx] : -2);   // the value looked for among p_c
+    const int lim = want_last ? idx : idx - 1;                          // highest step that may count
+    int best = -1;
+    for (int base = 0; base <= imax; base += 2048) {
+        const int cnt = min(2048, n - base);
+        __syncthreads();
+        for (int k = threadIdx.x; k < 2048; k += 256) s_piv[k] = (k < cnt) ? ipiv[base + k] : -1;
+        __syncthreads();
+        // 16 entries per trip: four independent 16-byte LDS reads in flight, then compares; ascending
+        // order, the last match wins
+        const int top = min(2047, imax - base) | 15;
+        for (int k = 16 * sub; k <= top; k += 64) {
+            const int4 p0 = *(const int4 *)&s_piv[k], p1 = *(const int4 *)&s_piv[k + 4];
+            const int4 p2 = *(const int4 *)&s_piv[k + 8], p3 = *(const int4 *)&s_piv[k + 12];
+            const int room = lim - (base + k);      // entries 0..room of this trip may count
+            if (room < 0) break;
+            int m = -1;                               // highest matching entry of the trip
+            m = (p0.x == key) ? 0 : m;   m = (p0.y == key) ? 1 : m;   m = (p0.z == key) ? 2 : m;   m = (p0.w == key) ? 3 : m;
+            m = (p1.x == key) ? 4 : m;   m = (p1.y == key) ? 5 : m;   m = (p1.z == key) ? 6 : m;   m = (p1.w == key) ? 7 : m;
+            m = (p2.x == key) ? 8 : m;   m = (p2.y == key) ? 9 : m;   m = (p2.z == key) ? 10 : m;  m = (p2.w == key) ? 11 : m;
+            m = (p3.x == key) ? 12 : m;  m = (p3.y == key) ? 13 : m;  m = (p3.z == key) ? 14 : m;  m = (p3.w == key) ? 15 : m;
+            if (m >= 0) {
+                if (m <= room) {
+                    best = base + k + m;
+                } else {   // rare: the trip straddles the limit -- redo it entry by entry
+                    for (int e = 0; e <= room && e < 16; ++e)
+                        if (s_piv[k + e] == key) best = base + k + e;
+                }
+            }
+        }
+    }
+    best = max(best, __shfl_xor(best, 1, 64));
+    best = max(best, __shfl_xor(best, 2, 64));
+    if (idx < n && sub == 0) (want_last ? last_target : prev_same)[idx] = best;
+}
+
+__global__ __launch_bounds__(256) void perm_chase_kernel(int n, const int32_t *__restrict__ ipiv,
+                                                         const int32_t *__restrict__ last_target,
+                                                         const int32_t *__restrict__ prev_same,
+                                                         int32_t *__restrict__ perm) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    int v = ipiv[k], bound = k;
+    if (v < 0 || v >= n) { perm[k] = k; return; }   // not a valid interchange list: leave the row in place
+    for (int hops = 0; hops < n; ++hops) {          // terminates: bound strictly decreases
+        int c = last_target[v];
+        while (c >= bound) c = prev_same[c];
+        if (c < 0) break;
+        v = c;
+        bound = c;
+    }
+    perm[k] = v;
+}
+
 int launch_ipiv_to_perm(lsx_handle_t h, int n, const int32_t *d_ipiv, int32_t *d_perm) {
     if (n <= 0) return LSX_OK;
-    hipLaunchKernelGGL(ipiv_to_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_ipiv,
-                       d_perm);
+    const size_t need = 2 * sizeof(int32_t) * (size_t)n;
+    if (h->scratch && h->scratch_bytes >= need) {
+        // the two index arrays live in the handle's scratch (every later user of it is stream-ordered)
+        int32_t *last_target = (int32_t *)h->scratch, *prev_same = last_target + n;
+        hipLaunchKernelGGL(perm_index_kernel, dim3((n + 63) / 64, 2), dim3(256), 0, h->stream, n, d_ipiv, last_target,
+                           prev_same);
+        hipLaunchKernelGGL(perm_chase_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_ipiv, last_target,
+                           prev_same, d_perm);
+    } else {
+        hipLaunchKernelGGL(ipiv_to_perm_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, d_ipiv, d_perm);
+    }
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -680,6 +802,7 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
     template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
+    template int launch_trtri_both<T>(lsx_handle_t, int, const T *, int, T *, T *);               \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
                                       int);                                                       \
     template int launch_set_identity_perm<T>(lsx_handle_t, int, const int32_t *, T *, int);       \

@@ -389,8 +389,7 @@ int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B
     ProfScope ps(h, LSX_PROF_TRSM, 2.0 * n * (double)n * nrhs, 2.0 * sizeof(T) * n * (double)n);
     const size_t shm_m = (size_t)4 * VH * VLD * sizeof(T);
     LSX_HIP(hipFuncSetAttribute((const void *)merge128_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_m));
-    LSX_TRY(launch_trtri<T>(h, 1, n, LU, lda, inv64L));
-    LSX_TRY(launch_trtri<T>(h, 0, n, LU, lda, inv64U));
+    LSX_TRY(launch_trtri_both<T>(h, n, LU, lda, inv64L, inv64U));
     // every workgroup must be resident at once; at 8 right-hand sides and large n the per-step path is
     // as fast (the LDS traffic of the 8-wide update dominates either way)
     if (h->trsv_mode == 1 && (n + CB - 1) / CB <= h->num_cu && (nrhs <= 4 || n <= 6144)) {

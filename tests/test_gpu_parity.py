@@ -661,3 +661,33 @@ def test_cooperative_triangular_solve_fp32(la, n, nrhs):
     # norm-wise backward error of the fp32 solve
     resid = np.linalg.norm(A @ x1.astype(np.float64) - B) / (np.linalg.norm(A) * np.linalg.norm(x1) + np.linalg.norm(B))
     assert resid < 1e-4
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 129, 300, 1000, 2049, 5000])
+@pytest.mark.parametrize("pattern", ["random", "all_last", "identity", "next", "clustered"])
+def test_interchange_list_to_permutation(la, n, pattern):
+    """ipiv -> perm conversion (index arrays + chase) against the sequential definition, through getrs on
+    an identity factor: x = P b.  Includes lists that make the chase long (every step picks the last row)."""
+    from linalg_solver_amd import dense
+
+    rng = np.random.default_rng(n)
+    k = np.arange(n)
+    if pattern == "random":
+        ipiv = rng.integers(k, n)
+    elif pattern == "all_last":
+        ipiv = np.full(n, n - 1)
+    elif pattern == "identity":
+        ipiv = k.copy()
+    elif pattern == "next":
+        ipiv = np.minimum(k + 1, n - 1)
+    else:
+        ipiv = np.minimum(k + rng.integers(0, 3, n), n - 1)
+    for nrhs in (1, 9):     # the few-RHS and the many-RHS paths
+        b = rng.uniform(-1, 1, (n, nrhs))
+        want = b.copy()
+        for i in range(n):
+            p = int(ipiv[i])
+            if p != i:
+                want[[i, p]] = want[[p, i]]
+        got = dense.lu_solve(np.eye(n), ipiv.astype(np.int32), b)
+        assert np.array_equal(got, want), f"nrhs={nrhs}"
