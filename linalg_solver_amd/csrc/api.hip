@@ -256,8 +256,12 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
             const int jb = (w - j < nb) ? w - j : nb;
             T *Acc = A + (size_t)c * lda + c;
             LSX_TRY(launch_panel<T>(h, n - c, jb, Acc, lda, c, d_ipiv + c, d_info));
-            LSX_TRY(apply_panel_swaps<T>(h, c, A, lda, c, jb, d_ipiv + c));                      // left
-            LSX_TRY(apply_panel_swaps<T>(h, n - c - jb, A + c + jb, lda, c, jb, d_ipiv + c));  // right
+            if (h->moves_valid) {   // left and right of the panel in one launch
+                LSX_TRY(launch_laswp_moves_around<T>(h, n, A, lda, c, c, jb));
+            } else {
+                LSX_TRY(apply_panel_swaps<T>(h, c, A, lda, c, jb, d_ipiv + c));                      // left
+                LSX_TRY(apply_panel_swaps<T>(h, n - c - jb, A + c + jb, lda, c, jb, d_ipiv + c));  // right
+            }
             const int inner = w - j - jb;  // columns of the super-block still to be factored
             if (inner > 0) {
                 T *A12 = A + (size_t)c * lda + c + jb;

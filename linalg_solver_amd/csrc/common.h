@@ -155,6 +155,8 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // same interchanges from the gather list h->moves (written by the cooperative panel kernel)
 template <typename T>
 int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
+template <typename T>
+int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, int hole_at, int hole_w);
 // Tinv (ceil(jb/64) blocks of 64x64) <- inverses of the 64x64 diagonal blocks of the
 // unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.
 template <typename T>

@@ -134,7 +134,8 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // workgroup touches these columns.  Each row segment is a 256-byte run.
 template <typename T, int CW>
 __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
-                                                          const int2 *__restrict__ moves) {
+                                                          const int2 *__restrict__ moves, int hole_at,
+                                                          int hole_w) {
     __shared__ int s_dst[256], s_src[256];
     __shared__ int s_n;
     const int tid = threadIdx.x;
@@ -155,11 +156,14 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
     constexpr int RP = 256 / CW;        // rows per pass
     constexpr int NP = 256 / RP;        // passes (max moves / RP)
     const bool cok = c0 + tc < ncols;
+    // logical column -> matrix column: the hole_w columns at hole_at (the panel itself, already in
+    // final order) are skipped, so the columns left and right of a panel take ONE launch
+    const int col = c0 + tc + ((c0 + tc >= hole_at) ? hole_w : 0);
     T v[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int d = tr + RP * i;
-        if (cok && d < nmv) v[i] = A[(size_t)(row0 + s_src[d]) * lda + c0 + tc];
+        if (cok && d < nmv) v[i] = A[(size_t)(row0 + s_src[d]) * lda + col];
     }
     // a row may be the source of one move and the destination of another: every load of the
     // chunk must have returned before any thread of the workgroup stores
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int d = tr + RP * i;
-        if (cok && d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + c0 + tc] = v[i];
+        if (cok && d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + col] = v[i];
     }
 }
 
@@ -177,7 +181,20 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
     constexpr int CW = 32;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
     hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
-                       ncols, A, lda, row0, (const int2 *)h->moves);
+                       ncols, A, lda, row0, (const int2 *)h->moves, 0x7fffffff, 0);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// all columns of an n-column matrix except the hole_w columns starting at hole_at, one launch
+template <typename T>
+int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, int hole_at, int hole_w) {
+    const int ncols = n - hole_w;
+    if (ncols <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
+    constexpr int CW = 32;
+    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
+                       ncols, A, lda, row0, (const int2 *)h->moves, hole_at, hole_w);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -801,6 +818,7 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     template int launch_fill<T>(lsx_handle_t, int, uint64_t, int, int, T *, int, int, int);       \
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
     template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
+    template int launch_laswp_moves_around<T>(lsx_handle_t, int, T *, int, int, int, int);        \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trtri_both<T>(lsx_handle_t, int, const T *, int, T *, T *);               \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
