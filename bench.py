@@ -280,17 +280,37 @@ def main():
             ts.append(time.perf_counter() - t0)
         out["config2_4096"] = {"lu_ms": lu4096 * 1e3, "lu_gflops": lu_flops(n2) / lu4096 / 1e9,
                                "solve_1rhs_latency_ms": min(ts[1:]) * 1e3}
+        # parity check inside the run: factor a fresh matrix of the benchmark shape, solve one
+        # right-hand side, report info and the scaled residual against the unfactored copy
+        A_chk = torch.empty(n, n, dtype=tdt, device="cuda")
+        dev.fill_(A_chk, gen.U11, 12345)
+        LU_chk = A_chk.clone()
+        ip_chk = torch.empty(n, dtype=torch.int32, device="cuda")
+        info_chk = torch.zeros(1, dtype=torch.int32, device="cuda")
+        dev.getrf_(LU_chk, ip_chk, info_chk)
+        b_chk = torch.empty(n, 1, dtype=tdt, device="cuda")
+        dev.fill_(b_chk, gen.U11, 12345, col_off=gen.RHS_COL)
+        x_chk = b_chk.clone()
+        dev.getrs_(LU_chk, ip_chk, x_chk)
+        r = (A_chk.double() @ x_chk.double() - b_chk.double()).abs().max().item()
+        scale = (A_chk.double().abs().sum(dim=1).max().item() * x_chk.double().abs().max().item()
+                 + b_chk.double().abs().max().item())
+        bound = 1e-9 if args.dtype == "f64" else 1e-4
+        out["check"] = {"info": int(info_chk.item()), "solve_scaled_residual": r / scale, "bound": bound,
+                        "ok": bool(int(info_chk.item()) == 0 and r / scale < bound)}
         if args.dtype == "f64":
-            # config #3: inverse from the factors of the last benchmark matrix
-            LU = mats[-1]
+            # config #3: inverse from the factors just checked
+            LU = LU_chk
             inv = torch.empty(n, n, dtype=tdt, device="cuda")
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            dev.getri(LU, ipiv, inv)
+            dev.getri(LU, ip_chk, inv)
             torch.cuda.synchronize()
             t_inv = time.perf_counter() - t0
+            ident_err = (A_chk @ inv - torch.eye(n, dtype=tdt, device="cuda")).abs().max().item()
             out["config3_inverse"] = {"getri_ms": t_inv * 1e3, "lu_plus_inverse_ms": t_inv * 1e3 + ms_per_step,
-                                      "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9}
+                                      "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9,
+                                      "max_abs_A_inv_minus_I": ident_err}
     if world == 1 and not args.no_extras and args.dtype == "f64":
         # config #1 (the reference's own CPU-runnable case): 64 x 64 ints in [-5,5] as floats + rhs through
         # the Matrix surface -- fast path, traced path (reference-order arithmetic + step list) and traced
