@@ -1,4 +1,6 @@
-"""The sharded (multi-GPU) LU driver on CPU: gloo, world_size 2 and 3.
+"""The sharded (multi-GPU) LU driver on CPU: gloo, world_size 2, 3 and 4 (look-ahead included: the next
+owner factors and broadcasts its panel before it finishes the update; more blocks than ranks, fewer blocks
+than ranks, ragged last block).
 
 Checks the distribution logic of linalg_solver_amd/dist.py -- block-cyclic ownership,
 local offsets, one panel broadcast per step, interchanges on the non-owned columns --
@@ -57,7 +59,8 @@ def _worker(rank, world, port, n, nb, kind):
 
 
 @pytest.mark.parametrize("world,n,nb,kind", [(2, 96, 32, gen.U11), (2, 200, 32, gen.U11), (2, 130, 64, gen.INT5),
-                                             (3, 150, 16, gen.U11), (2, 40, 64, gen.U11)])
+                                             (3, 150, 16, gen.U11), (2, 40, 64, gen.U11),
+                                             (4, 260, 32, gen.U11), (4, 97, 16, gen.INT5), (3, 64, 64, gen.U11)])
 def test_sharded_lu_matches_single_process_twin(world, n, nb, kind):
     mp.spawn(_worker, args=(world, _free_port(), n, nb, kind), nprocs=world, join=True)
 
