@@ -301,6 +301,10 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         const int txo = j >> 3;
         const int wo = (txo * NTY) >> 6, lane0 = (txo * NTY) & 63;
         const bool more = j + 1 < jb;
+        // block boundary inside one wave: column j + 1 belongs to the next thread column, whose lanes sit
+        // in this very wave (3 boundaries in 4 at NT = 256, every other one at NT = 512) -- the chain
+        // continues in the wave as within a block, no extra barrier
+        const bool same_wave_next = (JC == 7) && more && ((((txo + 1) * NTY) >> 6) == wo);
         if (wave == wo) {
             if (DBG && JC == 0) tlast = __builtin_amdgcn_s_memrealtime();
             // ---------------- O1: all headers of column j (two shots are already in flight)
@@ -399,8 +403,26 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             }
             STAMP(2)
             int cl = -1;
-            if (JC < 7 && more)
+            if (JC < 7 && more) {
                 cl = choose_and_announce(std::integral_constant<int, (JC < 7 ? JC + 1 : 7)>{}, j + 1, own, lane0);
+            } else if (same_wave_next) {
+                // the lanes of thread column txo + 1: multipliers from LDS (written above by this wave:
+                // LDS is in order within a wave), the pivot row's entry of column j + 1 by readlane
+                const int txn = txo + 1;
+                const bool own2 = tx == txn;
+                const T un = readlane_t((txn >= 8) ? u1 : u0, (8 * txn) & 63);
+                if (own2) {
+                    if (valid && bg == g) {
+                        const int wl = win - base;
+                        if ((wl % NTY) == ty) frozen |= 1u << ((wl / NTY) & 31);
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int r = 0; r < RT; ++r) a[r][0] -= s_l[par][NTY * r + ty] * un;
+                    }
+                }
+                cl = choose_and_announce(std::integral_constant<int, 0>{}, j + 1, own2, (txn * NTY) & 63);
+            }
             if (lane == 0) s_info[par] = make_int4(valid ? win : -1, (act ? 1 : 0) | (failed_now ? 2 : 0), cl, 0);
             if (failed_now && !failed && lane == 0) atomicExch(status, 1);
             STAMP(3)
@@ -413,7 +435,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         const bool act = (inf.y & 1) != 0;
         failed |= (inf.y & 2) != 0;
         const bool valid = wrow >= 0;
-        const bool next_here = JC < 7 && more;   // the next column has the same owner wave
+        const bool next_here = (JC < 7 && more) || same_wave_next;   // the next column has the same owner wave
         if (next_here && wave == wo) shot_async(hA, j + 1);
         // bookkeeping by a lane of the wave AFTER the owner wave: never on the critical wave, and its
         // global accesses (ipiv, info) never queue behind the owner wave's shots
@@ -434,15 +456,19 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             for (int r = 0; r < RT; ++r) l[r] = s_l[par][NTY * r + ty];
 #pragma unroll
             for (int c = 0; c < 8; ++c) u[c] = s_u[par][8 * tx + c];
+            // column 0 of the next thread column is already up to date when its wave handled the boundary
+            const bool skip0 = same_wave_next && tx == txo + 1;
 #pragma unroll
-            for (int r = 0; r < RT; ++r)
+            for (int r = 0; r < RT; ++r) {
+                a[r][0] = skip0 ? a[r][0] : a[r][0] - l[r] * u[0];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) a[r][c] -= l[r] * u[c];
+                for (int c = 1; c < 8; ++c) a[r][c] -= l[r] * u[c];
+            }
         }
         if (next_here && wave == wo) shot_async(hB, j + 1);
         if (next_here) publish_row(j + 1, inf.z);
         if (wave == wo) STAMP(5)
-        if (JC == 7 && more) {
+        if (JC == 7 && more && !same_wave_next) {
             block_start(j + 1);
             if (wave == wo) STAMP(6)
         }
