@@ -23,8 +23,10 @@
 //   all waves    apply the rank-1 update to the columns right of the owner block, freeze the pivot
 //                row, and the thread row holding the new candidate publishes it as granules --
 //                all of this while the next header exchange is in flight.
-// Every eighth column the next column lives in another thread column: its owner reads the
-// multipliers from LDS after the barrier and starts the chain there (one extra barrier).
+// Every eighth column the next column lives in another thread column.  If its lanes sit in the same
+// wave the chain continues there (multipliers through LDS, which is in order within a wave); otherwise
+// the new owner wave reads the multipliers from LDS after the barrier and starts the chain there (one
+// extra barrier).
 //
 // Arithmetic per element is the same sequence of fused multiply-adds as the other panel modes
 // (same multipliers from the same fast_recip), so the factors are bit-identical to theirs.
