@@ -426,16 +426,44 @@ __global__ __launch_bounds__(256) void trsm_block2_kernel(int lower, int jb, int
     const int c0 = blockIdx.x * CWT;
     // order of the two 64-row blocks: lower = (0 then 1), upper = (1 then 0)
     const int b_first = lower ? 0 : 1, b_second = lower ? 1 : 0;
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int i = e / TB, j = e % TB;
-        T0[i * TLD + j] = Tinv[(size_t)b_first * TB * TB + e];
-        T2[i * TLD + j] = Tinv[(size_t)b_second * TB * TB + e];
-        const int gi = b_second * TB + i, gj = b_first * TB + j;
-        T1[i * TLD + j] = (gi < jb && gj < jb) ? Tm[(size_t)gi * ldt + gj] : T(0);
-    }
-    for (int e = tid; e < 128 * CWT; e += 256) {
-        const int i = e / CWT, j = e % CWT;
-        Bs[i * BLD + j] = (i < jb && c0 + j < ncols) ? B[(size_t)i * ldb + c0 + j] : T(0);
+    typedef T v2t __attribute__((ext_vector_type(2)));
+    const bool fast = (jb == 128) && (c0 + CWT <= ncols) && (((size_t)Tm | (size_t)Tinv | (size_t)B) % 16 == 0) &&
+                      (ldt % 2 == 0) && (ldb % 2 == 0);
+    if (fast) {
+        // complete tile: all 32 sixteen-byte loads of a thread are in flight before the first LDS write
+        v2t r0[8], r1[8], r2[8], rb[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);          // element pair inside a 64 x 64 block
+            const int i = e / TB, j = e % TB;
+            r0[q] = *(const v2t *)(Tinv + (size_t)b_first * TB * TB + e);
+            r2[q] = *(const v2t *)(Tinv + (size_t)b_second * TB * TB + e);
+            r1[q] = *(const v2t *)(Tm + (size_t)(b_second * TB + i) * ldt + b_first * TB + j);
+            const int eb = 2 * (tid + 256 * q);         // element pair inside the 128 x CWT chunk
+            rb[q] = *(const v2t *)(B + (size_t)(eb / CWT) * ldb + c0 + eb % CWT);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            const int i = e / TB, j = e % TB;
+            T0[i * TLD + j] = r0[q][0]; T0[i * TLD + j + 1] = r0[q][1];
+            T2[i * TLD + j] = r2[q][0]; T2[i * TLD + j + 1] = r2[q][1];
+            T1[i * TLD + j] = r1[q][0]; T1[i * TLD + j + 1] = r1[q][1];
+            const int bi = e / CWT, bj = e % CWT;
+            Bs[bi * BLD + bj] = rb[q][0]; Bs[bi * BLD + bj + 1] = rb[q][1];
+        }
+    } else {
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int i = e / TB, j = e % TB;
+            T0[i * TLD + j] = Tinv[(size_t)b_first * TB * TB + e];
+            T2[i * TLD + j] = Tinv[(size_t)b_second * TB * TB + e];
+            const int gi = b_second * TB + i, gj = b_first * TB + j;
+            T1[i * TLD + j] = (gi < jb && gj < jb) ? Tm[(size_t)gi * ldt + gj] : T(0);
+        }
+        for (int e = tid; e < 128 * CWT; e += 256) {
+            const int i = e / CWT, j = e % CWT;
+            Bs[i * BLD + j] = (i < jb && c0 + j < ncols) ? B[(size_t)i * ldb + c0 + j] : T(0);
+        }
     }
     __syncthreads();
     typename MfmaS<T>::acc_t acc[2];
@@ -464,6 +492,17 @@ __global__ __launch_bounds__(256) void trsm_block2_kernel(int lower, int jb, int
 #pragma unroll
         for (int r = 0; r < 4; ++r) B2[(16 * wave + MfmaS<T>::crow(lane, r)) * BLD + 16 * t + lc] = acc[t][r];
     __syncthreads();
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            const int bi = e / CWT, bj = e % CWT;
+            v2t x;
+            x[0] = Bs[bi * BLD + bj]; x[1] = Bs[bi * BLD + bj + 1];
+            *(v2t *)(B + (size_t)bi * ldb + c0 + bj) = x;
+        }
+        return;
+    }
     for (int e = tid; e < 128 * CWT; e += 256) {
         const int i = e / CWT, j = e % CWT;
         if (i < jb && c0 + j < ncols) B[(size_t)i * ldb + c0 + j] = Bs[i * BLD + j];
