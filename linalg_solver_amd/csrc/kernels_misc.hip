@@ -237,18 +237,39 @@ __global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * TB;
     // load (identity outside the matrix / outside the triangle)
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int i = e / TB, j = e % TB;
-        const int gi = b0 + i, gj = b0 + j;
-        T v = (i == j) ? T(1) : T(0);
-        if (gi < jb && gj < jb) {
-            if (lower) {
-                if (j < i) v = Tm[(size_t)gi * ldt + gj];
-            } else {
-                if (j >= i) v = Tm[(size_t)gi * ldt + gj];
+    typedef T v2t __attribute__((ext_vector_type(2)));
+    const bool fast = (b0 + TB <= jb) && ((size_t)Tm % 16 == 0) && (ldt % 2 == 0) && ((size_t)Tinv % 16 == 0);
+    if (fast) {   // complete block: 8 sixteen-byte loads per thread, all in flight, masked afterwards
+        v2t r[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            r[q] = *(const v2t *)(Tm + (size_t)(b0 + e / TB) * ldt + b0 + e % TB);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            const int i = e / TB, j = e % TB;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const bool inside = lower ? (j + d < i) : (j + d >= i);
+                X[i * TLD + j + d] = inside ? r[q][d] : ((i == j + d) ? T(1) : T(0));
             }
         }
-        X[i * TLD + j] = v;
+    } else {
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int i = e / TB, j = e % TB;
+            const int gi = b0 + i, gj = b0 + j;
+            T v = (i == j) ? T(1) : T(0);
+            if (gi < jb && gj < jb) {
+                if (lower) {
+                    if (j < i) v = Tm[(size_t)gi * ldt + gj];
+                } else {
+                    if (j >= i) v = Tm[(size_t)gi * ldt + gj];
+                }
+            }
+            X[i * TLD + j] = v;
+        }
     }
     __syncthreads();
     // 16 x 16 diagonal blocks: thread (blk, col) solves one column by substitution
@@ -297,6 +318,17 @@ __global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T
                 lds_gemm_tile<T>(s, s, s, P11, TLD, W, TLD, Off, TLD, T(-1), wave, 4, lane);
             __syncthreads();
         }
+    }
+    if (fast) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = 2 * (tid + 256 * q);
+            v2t x;
+            x[0] = X[(e / TB) * TLD + e % TB];
+            x[1] = X[(e / TB) * TLD + e % TB + 1];
+            *(v2t *)(Tinv + (size_t)blockIdx.x * TB * TB + e) = x;
+        }
+        return;
     }
     for (int e = tid; e < TB * TB; e += 256) {
         const int i = e / TB, j = e % TB;
