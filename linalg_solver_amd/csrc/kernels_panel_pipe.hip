@@ -148,12 +148,29 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
 
     // ---- load the slice (rows >= m and columns >= jb read as zero)
     T a[RT][8];
+    typedef T v2t __attribute__((ext_vector_type(2)));
+    // full-width panel with 16-byte aligned rows: 16-byte accesses (a thread's 8 entries are contiguous)
+    const bool wide = (jb == PC_COLS) && ((size_t)P % 16 == 0) && (ldp % 2 == 0);
+    if (wide) {
 #pragma unroll
-    for (int r = 0; r < RT; ++r) {
-        const int gi = base + NTY * r + ty;
-        const T *src = P + (size_t)gi * ldp + 8 * tx;
+        for (int r = 0; r < RT; ++r) {
+            const int gi = base + NTY * r + ty;
+            const T *src = P + (size_t)(gi < m ? gi : 0) * ldp + 8 * tx;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
+            for (int c = 0; c < 8; c += 2) {
+                const v2t v = *(const v2t *)(src + c);
+                a[r][c] = gi < m ? v[0] : T(0);
+                a[r][c + 1] = gi < m ? v[1] : T(0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int gi = base + NTY * r + ty;
+            const T *src = P + (size_t)gi * ldp + 8 * tx;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) a[r][c] = (gi < m && 8 * tx + c < jb) ? src[c] : T(0);
+        }
     }
     for (int t = tid; t < PC_COLS; t += NT) { s_topid[t] = t; s_postop[t] = t; }
     for (int t = tid; t < RB; t += NT) s_order[t] = -1;
@@ -518,9 +535,18 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
             const int ord = s_order[lr];
             const int dest = ord >= 0 ? ord : (gi < jb ? s_postop[gi] : gi);
             T *dst = P + (size_t)dest * ldp + 8 * tx;
+            if (wide) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (8 * tx + c < jb) dst[c] = a[r][c];
+                for (int c = 0; c < 8; c += 2) {
+                    v2t v;
+                    v[0] = a[r][c]; v[1] = a[r][c + 1];
+                    *(v2t *)(dst + c) = v;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (8 * tx + c < jb) dst[c] = a[r][c];
+            }
         }
     }
 }
