@@ -132,10 +132,14 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // flight), the workgroup synchronises (a row can be source and destination of different moves),
 // then everything is stored; a workgroup owns a 32-column chunk for every move, so no other
 // workgroup touches these columns.  Each row segment is a 256-byte run.
-template <typename T, int CW>
-__global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
+// VW = elements per lane (1, or 2 = one 16-byte access for fp64): with VW = 2 ncols, lda, hole_at and hole_w
+// are counted in PAIRS of columns and A is read as pairs (the caller checks evenness and alignment)
+template <typename T, int CW, int VW>
+__global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A_, int lda, int row0,
                                                           const int2 *__restrict__ moves, int hole_at,
                                                           int hole_w) {
+    typedef T vt __attribute__((ext_vector_type(VW)));
+    vt *__restrict__ A = (vt *)A_;
     __shared__ int s_dst[256], s_src[256];
     __shared__ int s_n;
     const int tid = threadIdx.x;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
     // logical column -> matrix column: the hole_w columns at hole_at (the panel itself, already in
     // final order) are skipped, so the columns left and right of a panel take ONE launch
     const int col = c0 + tc + ((c0 + tc >= hole_at) ? hole_w : 0);
-    T v[NP];
+    vt v[NP];
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int d = tr + RP * i;
@@ -180,7 +184,7 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
     if (ncols <= 0) return LSX_OK;
     constexpr int CW = 32;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
-    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
+    hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 1>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
                        ncols, A, lda, row0, (const int2 *)h->moves, 0x7fffffff, 0);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
@@ -193,7 +197,15 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
     if (ncols <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
     constexpr int CW = 32;
-    hipLaunchKernelGGL((laswp_moves_kernel<T, CW>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
+    if (sizeof(T) == 8 && ((size_t)A % 16 == 0) && lda % 2 == 0 && n % 2 == 0 && hole_at % 2 == 0 && hole_w % 2 == 0) {
+        // 16 bytes per lane: the matrix as pairs of columns
+        constexpr int CW = 16;   // pairs: the same 32 columns per workgroup, so the grid still covers the chip
+        hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 2>), dim3((ncols / 2 + CW - 1) / CW), dim3(256), 0, h->stream,
+                           ncols / 2, A, lda / 2, row0, (const int2 *)h->moves, hole_at / 2, hole_w / 2);
+        LSX_HIP(hipGetLastError());
+        return LSX_OK;
+    }
+    hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 1>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
                        ncols, A, lda, row0, (const int2 *)h->moves, hole_at, hole_w);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
