@@ -52,6 +52,16 @@ struct Mfma<float> {
 
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) banks
+// A slab in LDS: k-rows in pairs, As[buf][k/2][(k%2) * (BM+LPAD) + m], each pair padded by 16 bytes.
+// A ds_write_b64 is banked (addr/4) mod 32 over groups of 16 lanes, and the staging map puts 8 k-pairs
+// x 2 rows in a group: with a pair stride of 0 (mod 32) dwords those were 8-way conflicts (47 % of all
+// LDS cycles in the PMC run); a stride of 4 (mod 32) dwords makes them conflict-free.  The reads only
+// see the (k%2) stride within a lane group, which stays 32 (mod 64) dwords.
+template <typename T>
+struct ASlab {
+    static constexpr int PAIR = 2 * (BM + LPAD) + 16 / (int)sizeof(T);
+};
+#define AS_AT(buf, k, m) As[buf][(k) >> 1][((k) & 1) * (BM + LPAD) + (m)]
 
 // One 128 x 128 tile.  FULL = the tile lies inside the matrix, K is a multiple of BK and all
 // three operands are 16-byte aligned with even leading dimensions: every load/store is an
@@ -60,7 +70,7 @@ constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) ban
 template <typename T, bool FULL, int NWN>
 __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__restrict__ A, int lda,
                                               const T *__restrict__ B, int ldb, T *__restrict__ C, int ldc,
-                                              int m0, int n0, T (*As)[BK][BM + LPAD], T (*Bs)[BK][BN + LPAD],
+                                              int m0, int n0, T (*As)[BK / 2][ASlab<T>::PAIR], T (*Bs)[BK][BN + LPAD],
                                               int plus) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T v2 __attribute__((ext_vector_type(2)));
@@ -79,19 +89,28 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     // B slab 16 x 128: thread -> k (tid>>6) + (NT/64)*i, column pair (tid&63)*2
     const int a_row = tid >> 3, a_k = (tid & 7) * 2;
     const int b_k = tid >> 6, b_n = (tid & 63) * 2;
-    T ra[NL][2], rb[NL][2];
+    T ra0[NL][2], rb0[NL][2];   // one staging set: slab kt+1 is in flight under the MFMAs of slab kt
     const T sgn = plus ? T(1) : T(-1);
+    unsigned a_off[NL], b_off[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        a_off[i] = (unsigned)(a_row + (NT / 8) * i) * (unsigned)lda + a_k;
+        b_off[i] = (unsigned)(b_k + (NT / 64) * i) * (unsigned)ldb + b_n;
+    }
 
-    auto load_slab = [&](int k0) {
+    auto load_slab = [&](int k0, T (&ra)[NL][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
         if (FULL) {
+            // uniform 64-bit base + 32-bit lane offset: the addresses cost NL VGPRs per operand, not 2*NL per set
+            const T *Au = A + (size_t)m0 * lda + k0;
+            const T *Bu = B + (size_t)k0 * ldb + n0;
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const v2 v = *(const v2 *)(A + (size_t)(m0 + a_row + (NT / 8) * i) * lda + k0 + a_k);
+                const v2 v = *(const v2 *)(Au + a_off[i]);
                 ra[i][0] = v[0]; ra[i][1] = v[1];
             }
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
-                const v2 v = *(const v2 *)(B + (size_t)(k0 + b_k + (NT / 64) * i) * ldb + n0 + b_n);
+                const v2 v = *(const v2 *)(Bu + b_off[i]);
                 rb[i][0] = v[0]; rb[i][1] = v[1];
             }
         } else {
@@ -116,11 +135,11 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     // column n of the tile -> wave piece h = n/WN, c = (n%WN)/TN, t = n%TN -> LDS column WN*h + 16*t + c
     auto bperm = [](int n) { return (n / WN) * WN + 16 * (n % TN) + (n % WN) / TN; };
     const int bp0 = bperm(b_n), bp1 = bperm(b_n + 1);
-    auto store_slab = [&](int buf) {
+    auto store_slab = [&](int buf, T (&ra)[NL][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {  // sign folded into A: the k-loop then accumulates C -+ A*B
-            As[buf][a_k][a_row + (NT / 8) * i] = sgn * ra[i][0];
-            As[buf][a_k + 1][a_row + (NT / 8) * i] = sgn * ra[i][1];
+            AS_AT(buf, a_k, a_row + (NT / 8) * i) = sgn * ra[i][0];
+            AS_AT(buf, a_k + 1, a_row + (NT / 8) * i) = sgn * ra[i][1];
         }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
@@ -130,7 +149,8 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     };
 
     // first slab goes out before the C loads so both latencies overlap
-    load_slab(0);
+    const int nslab = (K + BK - 1) / BK;
+    load_slab(0, ra0, rb0);
 
     // ---- accumulators <- C.  Lane owns columns wn + TN*lc + t (t = N-tile index).
     acc_t acc[4][TN];
@@ -159,17 +179,19 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
             for (int t = 0; t < TN; ++t) acc[s][t][r] = v[t];
         }
 
-    const int nslab = (K + BK - 1) / BK;
-    store_slab(0);
+    // One slab of cover is enough: a 16-deep slab is 32 MFMAs of 64 cycles per wave, 1.7-3.4 us per
+    // workgroup with two workgroups sharing the SIMDs, against ~1 us for an L2 hit under load (a second
+    // register set in flight was tried: it spills at the 128-VGPR budget and cannot gain).
+    store_slab(0, ra0, rb0);
     __syncthreads();
     for (int kt = 0; kt < nslab; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nslab) load_slab((kt + 1) * BK);
+        if (kt + 1 < nslab) load_slab((kt + 1) * BK, ra0, rb0);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             T a[4], b[TN];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = As[buf][kk + lq][wm + 16 * s + lc];
+            for (int s = 0; s < 4; ++s) a[s] = AS_AT(buf, kk + lq, wm + 16 * s + lc);
 #pragma unroll
             for (int t = 0; t < TN; ++t) b[t] = Bs[buf][kk + lq][wn + 16 * t + lc];
 #pragma unroll
@@ -177,7 +199,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
 #pragma unroll
                 for (int t = 0; t < TN; ++t) acc[s][t] = Mfma<T>::mma(a[s], b[t], acc[s][t]);
         }
-        if (kt + 1 < nslab) store_slab(buf ^ 1);
+        if (kt + 1 < nslab) store_slab(buf ^ 1, ra0, rb0);
         __syncthreads();
     }
 
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
                                                           int tiles_n, int tm_off, int tn_off, int plus) {
-    __shared__ T As[2][BK][BM + LPAD];  // As[buf][k][m] = -A[m][k]
+    __shared__ T As[2][BK / 2][ASlab<T>::PAIR];  // AS_AT(buf, k, m) = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
     // ---- optional phase stagger (option "gemm_stagger", default 0).  Two workgroups share a CU;
