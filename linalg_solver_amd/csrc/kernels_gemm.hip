@@ -235,7 +235,8 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
 // interior kernel's register allocation is not set by the edge path (it spilled inside 128 VGPRs).
 // (tm_off, tn_off) shift the tile grid so edge strips can be covered by separate launches.
 template <typename T, int NWN, bool FULL>
-__global__ __launch_bounds__(128 * NWN, 2 * NWN / 2) void gemm_sub_kernel(int M, int N, int K,
+// waves per SIMD: 2 workgroups per CU, 3 for the fp32 8-wave form (70 VGPRs, 37 KB of LDS)
+__global__ __launch_bounds__(128 * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_kernel(int M, int N, int K,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
@@ -316,7 +317,8 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
         const int elems16 = 16 / (int)sizeof(T);
         const bool aligned = ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) &&
                              (lda % elems16 == 0) && (ldb % elems16 == 0) && (ldc % elems16 == 0) && (k % BK == 0);
-        // fp64: 8 waves (64x32 per wave, 4 waves/SIMD hide the C read); fp32: 4 waves measured faster
+        // fp64: 8 waves (64x32 per wave, 4 waves/SIMD hide the C read); fp32: 4 waves (64x64 per wave) --
+        // the 8-wave fp32 form at 3 workgroups/CU is +4 % standalone and equal over an LU, so it stays opt-in
         const int waves = h->gemm_waves ? h->gemm_waves : (sizeof(T) == 8 ? 8 : 4);
         const int fm = aligned ? m / BM : 0, fn = aligned ? n / BN : 0;  // complete tiles
         auto go = [&](bool full, int gm, int gn, int om, int on) {

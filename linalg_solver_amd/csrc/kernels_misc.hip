@@ -1,6 +1,7 @@
 // Supporting kernels: deterministic fills, row interchanges, triangular block
 // inverses + block solves, determinant reduction, permutation helpers.
 #include "common.h"
+#include <type_traits>
 
 namespace lsx {
 
@@ -132,13 +133,14 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // flight), the workgroup synchronises (a row can be source and destination of different moves),
 // then everything is stored; a workgroup owns a 32-column chunk for every move, so no other
 // workgroup touches these columns.  Each row segment is a 256-byte run.
-// VW = elements per lane (1, or 2 = one 16-byte access for fp64): with VW = 2 ncols, lda, hole_at and hole_w
-// are counted in PAIRS of columns and A is read as pairs (the caller checks evenness and alignment)
+// VW = elements per lane (1, or 16 bytes' worth: 2 in fp64, 4 in fp32): with VW > 1 ncols, lda, hole_at and hole_w
+// are counted in GROUPS of VW columns and A is read as such groups (the caller checks divisibility and alignment)
 template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A_, int lda, int row0,
                                                           const int2 *__restrict__ moves, int hole_at,
                                                           int hole_w) {
-    typedef T vt __attribute__((ext_vector_type(VW)));
+    typedef T vw_t __attribute__((ext_vector_type(VW > 1 ? VW : 2)));
+    typedef typename std::conditional<VW == 1, T, vw_t>::type vt;   // a 1-wide vector type ends up in scratch
     vt *__restrict__ A = (vt *)A_;
     __shared__ int s_dst[256], s_src[256];
     __shared__ int s_n;
@@ -197,11 +199,11 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
     if (ncols <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
     constexpr int CW = 32;
-    if (sizeof(T) == 8 && ((size_t)A % 16 == 0) && lda % 2 == 0 && n % 2 == 0 && hole_at % 2 == 0 && hole_w % 2 == 0) {
-        // 16 bytes per lane: the matrix as pairs of columns
-        constexpr int CW = 16;   // pairs: the same 32 columns per workgroup, so the grid still covers the chip
-        hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 2>), dim3((ncols / 2 + CW - 1) / CW), dim3(256), 0, h->stream,
-                           ncols / 2, A, lda / 2, row0, (const int2 *)h->moves, hole_at / 2, hole_w / 2);
+    constexpr int VW = 16 / (int)sizeof(T);   // 16 bytes per lane: the matrix as groups of 2 (fp64) or 4 (fp32) columns
+    if (((size_t)A % 16 == 0) && lda % VW == 0 && n % VW == 0 && hole_at % VW == 0 && hole_w % VW == 0) {
+        constexpr int CW = 32 / VW;   // the same 32 columns per workgroup, so the grid still covers the chip
+        hipLaunchKernelGGL((laswp_moves_kernel<T, CW, VW>), dim3((ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
+                           ncols / VW, A, lda / VW, row0, (const int2 *)h->moves, hole_at / VW, hole_w / VW);
         LSX_HIP(hipGetLastError());
         return LSX_OK;
     }
