@@ -276,7 +276,22 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
             T *Akk = A + (size_t)k * lda + k;
             T *A12 = A + (size_t)k * lda + k + w;
             LSX_TRY(launch_trtri<T>(h, 1, w, Akk, lda, Tinv));
-            LSX_TRY(launch_trsm_block<T>(h, 1, w, rest, Akk, lda, Tinv, A12, lda));
+            if (w > nb && nb % 64 == 0) {
+                // U12 of a super-block one panel at a time: 128-row block solve, then the rows of the later
+                // panels take the update of the earlier ones (a skinny MFMA update) before their own solve.
+                // A single w-row block solve does the same flops inside one workgroup per 32 columns and
+                // costs more than the deeper trailing update saves.
+                for (int j = 0; j < w; j += nb) {
+                    const int jb = (w - j < nb) ? w - j : nb;
+                    if (j > 0)
+                        LSX_TRY(launch_gemm_sub<T>(h, jb, rest, j, Akk + (size_t)j * lda, lda, A12, lda,
+                                                   A12 + (size_t)j * lda, lda));
+                    LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk + (size_t)j * lda + j, lda,
+                                                 Tinv + (size_t)(j / 64) * 4096, A12 + (size_t)j * lda, lda));
+                }
+            } else {
+                LSX_TRY(launch_trsm_block<T>(h, 1, w, rest, Akk, lda, Tinv, A12, lda));
+            }
             LSX_TRY(launch_gemm_sub<T>(h, rest, rest, w, A + (size_t)(k + w) * lda + k, lda, A12, lda,
                                        A + (size_t)(k + w) * lda + k + w, lda));
         }
