@@ -137,18 +137,23 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     };
     hipStream_t caller = h->stream;
     hipStream_t main_s = h->stream, side = h->side_stream;
-    const bool partitioned = h->lookahead == 2;
+    bool partitioned = h->lookahead == 2;
+    int slice_rt = 4;
     if (partitioned) {
         // the panel's workgroups (128 rows each) all need a CU of their own inside the panel's CU
         // set; one and a half times as many CUs as workgroups are reserved, in multiples of 32
-        const int G = (n - k0 + 127) / 128;
+        slice_rt = (n - k0 > 8192) ? 8 : 4;             // 256-row slices above 8192 rows: half the workgroups
+        const int G = (n - k0 + 32 * slice_rt - 1) / (32 * slice_rt);
         int pcus = ((G + G / 2 + 31) / 32) * 32;
         if (pcus > h->num_cu / 2) pcus = h->num_cu / 2;
-        if (pcus < G) { set_error("look-ahead partition: %d workgroups do not fit in %d CUs", G, pcus); return LSX_ERR_INTERNAL; }
         if (const char *e = getenv("LSX_PANEL_CUS")) pcus = atoi(e);  // diagnostics: force the split
-        LSX_TRY(ensure_partition(h, pcus));
-        main_s = h->part_update;
-        side = h->part_panel;
+        if (pcus < G) {
+            partitioned = false;   // the panel does not fit in half the chip: plain look-ahead
+        } else {
+            LSX_TRY(ensure_partition(h, pcus));
+            main_s = h->part_update;
+            side = h->part_panel;
+        }
     }
     struct Restore {  // the handle's stream is the update stream while this driver runs
         lsx_handle_t h; hipStream_t keep; int nt, rt;
@@ -157,7 +162,7 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     if (partitioned) {
         // every panel workgroup must be resident inside the panel's CU set: 128-row slices only
         h->panel_nt = 512;
-        h->panel_rt = 4;
+        h->panel_rt = slice_rt;
         LSX_HIP(hipEventRecord(h->ev_start, caller));
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_start, 0));
         h->stream = main_s;
@@ -241,13 +246,15 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
     T *Tinv = (T *)h->ws2;
     if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
-    // Look-ahead (panel k+1 on its own CU set under the update of step k) pays where the panel chain
-    // dominates AND the update still has enough work to hide: measured on MI355X it wins ~9 % around
-    // n = 8192, loses a few % below ~6000 (the tall-panel shape and the split update cost more than
-    // is hidden) and is a wash above ~10000 (the update dominates; it needs all CUs).
-    constexpr int LOOKAHEAD_MIN = 7168, LOOKAHEAD_MAX = 10240;
+    // Look-ahead (panel k+1 on a side stream under the update of step k; bit-identical factors).  Measured
+    // on MI355X with the pipelined panel, lookahead=1 against the sequential driver: n = 4096 -8 %,
+    // 6144 +0.5 %, 7168 +5 %, 8192 +8 %, 10240..16384 +11..12 %, 20480 +10 %.  Below ~6500 the shorter update
+    // no longer hides the panel and the split update costs more than it saves; in fp32 the update is half
+    // as long, so the break-even moves up (8192: -5 %, 10240: 0, 12288: +2.5 %, 16384: +6 %).
+    int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 11264;
+    if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) LOOKAHEAD_MIN = atoi(e);  // diagnostics
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
-    if (h->lookahead && n >= LOOKAHEAD_MIN && n <= LOOKAHEAD_MAX && h->kblock == 1) k_end = 0;
+    if (h->lookahead && n >= LOOKAHEAD_MIN && h->kblock == 1) k_end = 0;
     const int W = nb * h->kblock;
     for (int k = 0; k < k_end; k += W) {
         const int w = (n - k < W) ? n - k : W;  // width of this super-block

@@ -67,7 +67,7 @@ struct lsx_handle_s {
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 3;  // 0 = per-column launches, 1 = cooperative, 2 = blocked (experimental), 3 = pipelined
-    int lookahead = 0;   // 0: off; 1: panel k+1 on a side stream; 2: same, with the update and the panel on disjoint CU sets (+9 % at n~8192, bit-identical)
+    int lookahead = 1;   // 0: off; 1: panel k+1 on a high-priority side stream under the update of step k (n >= 7168: +5..12 %, bit-identical); 2: same, with the update and the panel on disjoint CU sets
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step

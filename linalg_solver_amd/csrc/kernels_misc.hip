@@ -181,24 +181,12 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
     }
 }
 
-template <typename T>
-int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
-    if (ncols <= 0) return LSX_OK;
-    constexpr int CW = 32;
-    ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
-    hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 1>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
-                       ncols, A, lda, row0, (const int2 *)h->moves, 0x7fffffff, 0);
-    LSX_HIP(hipGetLastError());
-    return LSX_OK;
-}
-
 // all columns of an n-column matrix except the hole_w columns starting at hole_at, one launch
 template <typename T>
 int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, int hole_at, int hole_w) {
     const int ncols = n - hole_w;
     if (ncols <= 0) return LSX_OK;
     ProfScope ps(h, LSX_PROF_LASWP, 0, 4.0 * sizeof(T) * 128 * (double)ncols);
-    constexpr int CW = 32;
     constexpr int VW = 16 / (int)sizeof(T);   // 16 bytes per lane: the matrix as groups of 2 (fp64) or 4 (fp32) columns
     if (((size_t)A % 16 == 0) && lda % VW == 0 && n % VW == 0 && hole_at % VW == 0 && hole_w % VW == 0) {
         constexpr int CW = 32 / VW;   // the same 32 columns per workgroup, so the grid still covers the chip
@@ -207,10 +195,17 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
         LSX_HIP(hipGetLastError());
         return LSX_OK;
     }
+    constexpr int CW = 32;
     hipLaunchKernelGGL((laswp_moves_kernel<T, CW, 1>), dim3((ncols + CW - 1) / CW), dim3(256), 0, h->stream,
                        ncols, A, lda, row0, (const int2 *)h->moves, hole_at, hole_w);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
+}
+
+// the same for a plain column range
+template <typename T>
+int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
+    return launch_laswp_moves_around<T>(h, ncols, A, lda, row0, 0, 0);
 }
 
 // ------------------------------------------------------------------ triangular 64-block inverse

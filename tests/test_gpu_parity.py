@@ -168,7 +168,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
         h.set_option("panel", 3)
         h.set_option("panel_rt", 4)
         h.set_option("panel_nt", 0)
-        h.set_option("lookahead", 0)
+        h.set_option("lookahead", 1)
         h.set_option("kblock", 1)
     assert np.array_equal(results[4][1], results[3][1]) and np.array_equal(results[4][0], results[3][0])
     # the blocked panel (mode 2) performs the same fused multiply-adds in the same order
@@ -191,7 +191,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     finally:
         h.set_option("panel_nt", 0)
         h.set_option("panel_rt", 4)
-        h.set_option("lookahead", 0)
+        h.set_option("lookahead", 1)
     # tile height and look-ahead do not change a single bit
     assert np.array_equal(results[1][1], results[0][1]) and np.array_equal(results[1][0], results[0][0])
     assert np.array_equal(results[2][1], results[3][1]) and np.array_equal(results[2][0], results[3][0])
@@ -580,7 +580,7 @@ def test_lookahead_variants_are_bit_identical_at_8192(dev):
             assert int(info.item()) == 0
             outs.append((LU, ipiv.clone()))
     finally:
-        dev.h.set_option("lookahead", 0)
+        dev.h.set_option("lookahead", 1)
     for LU, ipiv in outs[1:]:
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 

@@ -33,6 +33,7 @@ def timeit(fn, reps=5, warm=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="+")
+    ap.add_argument("--f32", action="store_true", help="lu: factor in fp32")
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--nb", type=int, default=128)
     args = ap.parse_args()
@@ -208,7 +209,7 @@ def main():
         dev.h.set_option("panel", 1)
     if "lu" in args.what:
         n = args.n
-        A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+        A0 = torch.empty(n, n, dtype=torch.float32 if args.f32 else torch.float64, device="cuda")
         dev.fill_(A0, gen.U11, 1)
         A = A0.clone()
         ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
@@ -234,7 +235,7 @@ def main():
                 pr = dev.h.prof_read()
                 print(f"getrf n={n} panel={mode} rt={rt} lookahead={look} nb={nb} kblock={kb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
                       + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()), flush=True)
-        dev.h.set_option("kblock", 1); dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 0)
+        dev.h.set_option("kblock", 1); dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 1)
         dev.h.set_option("nb", 128)
 
 
