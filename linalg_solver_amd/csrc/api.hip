@@ -96,13 +96,14 @@ static int apply_panel_swaps(lsx_handle_t h, int ncols, T *Acols, int lda, int r
 
 // ---------------------------------------------------------------- look-ahead LU driver
 // Right-looking LU with look-ahead depth 1.  The update of step k is split: the columns of
-// the NEXT panel are updated first, then that panel is factored on the high-priority side
-// stream while the main stream updates the rest of the trailing matrix.  The panel chain
+// the NEXT panel are updated first, then that panel is factored, all on the high-priority side
+// stream, while the main stream updates the rest of the trailing matrix.  The panel chain
 // (latency-bound: one cross-CU exchange per column) thus runs underneath the MFMA work.
-//   main:  wait P(k) | laswp | trsm | gemm(next panel cols) | record N(k) | gemm(rest) ...
-//   side:                                   wait N(k) | panel(k+1) | record P(k+1)
-// Disjointness: panel(k+1) owns columns [k+jb, k+2jb) x rows >= k+jb; gemm(rest) writes
-// columns >= k+2jb and reads L21 (columns [k,k+jb)) and U12 (rows [k,k+jb)).
+//   side:  panel(k) | trtri(k) | record P(k) | wait N(k-1) | laswp, trsm, gemm on the next panel's columns | panel(k+1)
+//   main:                         wait P(k)  | laswp, trsm, gemm on the other columns | left-hand laswp | record N(k)
+// (P(k) is recorded behind the next panel's column block when both streams share the CUs.)
+// Disjointness: the side stream's step k touches columns [k+jb, k+2jb); the main stream's step k writes
+// columns >= k+2jb and < k and reads L21 (columns [k,k+jb)), U12 (rows [k,k+jb)) and the block inverses.
 // Two streams masked to disjoint CU sets: `panel_cus` CUs for the panel, the rest for the update.
 static int ensure_partition(lsx_handle_t h, int panel_cus) {
     if (h->part_panel_cus == panel_cus && h->part_update && h->part_panel) return LSX_OK;
@@ -174,56 +175,71 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     // buffer while the update stream still applies panel p's interchanges to the left-hand columns,
     // which nothing later depends on and which therefore run AFTER the big update, in its slack.
     struct KeepMoves { lsx_handle_t h; ~KeepMoves() { h->moves = h->moves_buf[0]; } } keep_moves{h};
+    // The whole chain panel k -> panel k+1 stays on the side stream (no cross-stream hop on the critical
+    // path): inverse of panel k's diagonal blocks, then interchanges / U12 / update of the next panel's own
+    // column block, then panel k+1.  The main stream follows one event behind with the other columns.  The
+    // side stream must not touch the next panel's columns before the main stream's update of step k-1 has
+    // written them (ev_next, recorded long before it is needed: that update runs beside panel k); the block
+    // inverses alternate between two buffers because the main stream still reads step k's while the side
+    // stream writes step k+1's.
     int step = 0;
+    T *Tinv2[2] = {Tinv, Tinv + (size_t)((nb + 63) / 64) * 4096};
     {
         OnSide g(h, side);
         const int jb0 = (n - k0) < nb ? (n - k0) : nb;
         h->moves = h->moves_buf[step & 1];
         LSX_TRY(launch_panel<T>(h, n - k0, jb0, A + (size_t)k0 * lda + k0, lda, k0, d_ipiv + k0, d_info));
-        LSX_HIP(hipEventRecord(h->ev_panel, side));
     }
+    bool have_update = false;   // ev_next holds the end of the previous step's update
     for (int k = k0; k < n; k += nb, ++step) {
         const int jb = (n - k < nb) ? n - k : nb;
         T *Akk = A + (size_t)k * lda + k;
-        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));  // panel k is factored
+        T *Ti = Tinv2[step & 1];
         const bool mv_valid = h->moves_valid;
-        h->moves = h->moves_buf[step & 1];
         const int rest = n - k - jb;
         if (rest <= 0) {
+            LSX_HIP(hipEventRecord(h->ev_panel, side));
+            LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));  // the last panel is factored
+            h->moves = h->moves_buf[step & 1];
             LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
             break;
         }
         T *A12 = A + (size_t)k * lda + k + jb;
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
-        // the chain panel k -> panel k+1 is the critical path: only the next panel's own column block
-        // goes through interchanges / U12 / update before the side stream is released; the other columns
-        // follow while the panel runs
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
-        LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
-        LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Tinv));
-        LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Tinv, A12, lda));
-        LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
-        LSX_HIP(hipEventRecord(h->ev_next, main_s));
-        LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+        bool next_valid;
         {
             OnSide g(h, side);
+            LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
+            if (partitioned) LSX_HIP(hipEventRecord(h->ev_panel, side));   // panel k and its block inverses are done
+            if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+            h->moves = h->moves_buf[step & 1];
+            LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
+            LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
+            // Sharing the CUs, the big update would take the slots these small launches need (measured:
+            // the chain doubles); the main stream then starts behind the chain.  On disjoint CU sets it
+            // starts as soon as panel k and its block inverses are there.
+            if (!partitioned) LSX_HIP(hipEventRecord(h->ev_panel, side));
             h->moves = h->moves_buf[(step + 1) & 1];
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
-            LSX_HIP(hipEventRecord(h->ev_panel, side));
+            next_valid = h->moves_valid;
         }
-        const bool next_valid = h->moves_valid;
+        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+        h->moves = h->moves_buf[step & 1];   // panel k's list
+        h->moves_valid = mv_valid;
         if (rest > jb2) {
-            h->moves = h->moves_buf[step & 1];   // panel k's list again (the launch above switched it)
-            h->moves_valid = mv_valid;
             LSX_TRY(apply_panel_swaps<T>(h, rest - jb2, A + k + jb + jb2, lda, k, jb, d_ipiv + k));
-            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest - jb2, Akk, lda, Tinv, A12 + jb2, lda));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest - jb2, Akk, lda, Ti, A12 + jb2, lda));
             LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
         }
-        // panel k's interchanges on the columns left of it, from panel k's own list
-        h->moves = h->moves_buf[step & 1];
-        h->moves_valid = mv_valid;
+        // panel k's interchanges on the columns left of it, in the slack after the update
         LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
+        // recorded after the last reader of panel k's gather list: panel k+2 (launched by the side stream
+        // behind its wait on this event) writes the same buffer
+        LSX_HIP(hipEventRecord(h->ev_next, main_s));
+        have_update = true;
         h->moves_valid = next_valid;
     }
     if (partitioned) {  // hand the result back to the caller's stream
@@ -243,7 +259,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
                                   ((size_t)n / 32 + 2) * 5248 + 8192));
     const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
-    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv_elems * sizeof(T))));
+    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * sizeof(T))));   // x2: the look-ahead driver alternates
     T *Tinv = (T *)h->ws2;
     if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
     // Look-ahead (panel k+1 on a side stream under the update of step k; bit-identical factors).  Measured
