@@ -57,27 +57,29 @@ constexpr int LPAD = 16;  // (BM + LPAD) * sizeof(double) / 4 == 32 (mod 64) ban
 // x 2 rows in a group: with a pair stride of 0 (mod 32) dwords those were 8-way conflicts (47 % of all
 // LDS cycles in the PMC run); a stride of 4 (mod 32) dwords makes them conflict-free.  The reads only
 // see the (k%2) stride within a lane group, which stays 32 (mod 64) dwords.
-template <typename T>
+template <typename T, int BM_>
 struct ASlab {
-    static constexpr int PAIR = 2 * (BM + LPAD) + 16 / (int)sizeof(T);
+    static constexpr int PAIR = 2 * (BM_ + LPAD) + 16 / (int)sizeof(T);
 };
-#define AS_AT(buf, k, m) As[buf][(k) >> 1][((k) & 1) * (BM + LPAD) + (m)]
+#define AS_AT(buf, k, m) As[buf][(k) >> 1][((k) & 1) * (BM_ + LPAD) + (m)]
 
 // One 128 x 128 tile.  FULL = the tile lies inside the matrix, K is a multiple of BK and all
 // three operands are 16-byte aligned with even leading dimensions: every load/store is an
 // unpredicated 16-byte access.  Otherwise every element is bounds-checked (edge tiles, odd ld).
-// NWN = waves along N (2 or 4): the workgroup has 2*NWN waves, each owning a 64 x (128/NWN) piece.
-template <typename T, bool FULL, int NWN>
+// NWN = waves along N (2 or 4): the workgroup has (BM_/64)*NWN waves, each owning a 64 x (128/NWN) piece.
+// BM_ = tile height: 128, or 64 for skinny updates (half the waves, twice the workgroups).
+template <typename T, bool FULL, int NWN, int BM_>
 __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__restrict__ A, int lda,
                                               const T *__restrict__ B, int ldb, T *__restrict__ C, int ldc,
-                                              int m0, int n0, T (*As)[BK / 2][ASlab<T>::PAIR], T (*Bs)[BK][BN + LPAD],
+                                              int m0, int n0, T (*As)[BK / 2][ASlab<T, BM_>::PAIR], T (*Bs)[BK][BN + LPAD],
                                               int plus) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T v2 __attribute__((ext_vector_type(2)));
-    constexpr int NT = 128 * NWN;      // threads
+    constexpr int NT = BM_ * NWN;      // threads
     constexpr int WN = BN / NWN;       // wave tile width: 64 or 32
     constexpr int TN = WN / 16;        // N-tiles per wave: 4 or 2
-    constexpr int NL = 1024 / NT;      // staging loads per thread and operand: 4 or 2
+    constexpr int NLA = BM_ * 8 / NT;  // 16-byte staging loads per thread, A slab (BM_ x 16)
+    constexpr int NL = 1024 / NT;      // the same for the B slab (16 x 128): 4 or 2
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -89,22 +91,21 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     // B slab 16 x 128: thread -> k (tid>>6) + (NT/64)*i, column pair (tid&63)*2
     const int a_row = tid >> 3, a_k = (tid & 7) * 2;
     const int b_k = tid >> 6, b_n = (tid & 63) * 2;
-    T ra0[NL][2], rb0[NL][2];   // one staging set: slab kt+1 is in flight under the MFMAs of slab kt
+    T ra0[NLA][2], rb0[NL][2];   // one staging set: slab kt+1 is in flight under the MFMAs of slab kt
     const T sgn = plus ? T(1) : T(-1);
-    unsigned a_off[NL], b_off[NL];
+    unsigned a_off[NLA], b_off[NL];
 #pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        a_off[i] = (unsigned)(a_row + (NT / 8) * i) * (unsigned)lda + a_k;
-        b_off[i] = (unsigned)(b_k + (NT / 64) * i) * (unsigned)ldb + b_n;
-    }
+    for (int i = 0; i < NLA; ++i) a_off[i] = (unsigned)(a_row + (NT / 8) * i) * (unsigned)lda + a_k;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) b_off[i] = (unsigned)(b_k + (NT / 64) * i) * (unsigned)ldb + b_n;
 
-    auto load_slab = [&](int k0, T (&ra)[NL][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
+    auto load_slab = [&](int k0, T (&ra)[NLA][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
         if (FULL) {
             // uniform 64-bit base + 32-bit lane offset: the addresses cost NL VGPRs per operand, not 2*NL per set
             const T *Au = A + (size_t)m0 * lda + k0;
             const T *Bu = B + (size_t)k0 * ldb + n0;
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
+            for (int i = 0; i < NLA; ++i) {
                 const v2 v = *(const v2 *)(Au + a_off[i]);
                 ra[i][0] = v[0]; ra[i][1] = v[1];
             }
@@ -115,7 +116,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) {
+            for (int i = 0; i < NLA; ++i) {
                 const int row = m0 + a_row + (NT / 8) * i;
                 const int kk = k0 + a_k;
                 const T *p = A + (size_t)row * lda + kk;
@@ -135,9 +136,9 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     // column n of the tile -> wave piece h = n/WN, c = (n%WN)/TN, t = n%TN -> LDS column WN*h + 16*t + c
     auto bperm = [](int n) { return (n / WN) * WN + 16 * (n % TN) + (n % WN) / TN; };
     const int bp0 = bperm(b_n), bp1 = bperm(b_n + 1);
-    auto store_slab = [&](int buf, T (&ra)[NL][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
+    auto store_slab = [&](int buf, T (&ra)[NLA][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) {  // sign folded into A: the k-loop then accumulates C -+ A*B
+        for (int i = 0; i < NLA; ++i) {  // sign folded into A: the k-loop then accumulates C -+ A*B
             AS_AT(buf, a_k, a_row + (NT / 8) * i) = sgn * ra[i][0];
             AS_AT(buf, a_k + 1, a_row + (NT / 8) * i) = sgn * ra[i][1];
         }
@@ -234,14 +235,14 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
 // FULL = false: any tile, every access bounds-checked.  Two kernels rather than one branch so the
 // interior kernel's register allocation is not set by the edge path (it spilled inside 128 VGPRs).
 // (tm_off, tn_off) shift the tile grid so edge strips can be covered by separate launches.
-template <typename T, int NWN, bool FULL>
+template <typename T, int NWN, bool FULL, int BM_ = BM>
 // waves per SIMD: 2 workgroups per CU, 3 for the fp32 8-wave form (70 VGPRs, 37 KB of LDS)
-__global__ __launch_bounds__(128 * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_kernel(int M, int N, int K,
+__global__ __launch_bounds__(BM_ * NWN, (BM_ == 64) ? 2 : (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_kernel(int M, int N, int K,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
                                                           int tiles_n, int tm_off, int tn_off, int plus) {
-    __shared__ T As[2][BK / 2][ASlab<T>::PAIR];  // AS_AT(buf, k, m) = -A[m][k]
+    __shared__ T As[2][BK / 2][ASlab<T, BM_>::PAIR];  // AS_AT(buf, k, m) = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
     // ---- optional phase stagger (option "gemm_stagger", default 0).  Two workgroups share a CU;
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(128 * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) 
     const int gsize = min(tiles_m - first_m, GROUP);
     const int tile_m = first_m + (bid % per_group) % gsize;
     const int tile_n = (bid % per_group) / gsize;
-    const int m0 = (tile_m + tm_off) * BM, n0 = (tile_n + tn_off) * BN;
-    gemm_sub_tile<T, FULL, NWN>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, plus);
+    const int m0 = (tile_m + tm_off) * BM_, n0 = (tile_n + tn_off) * BN;
+    gemm_sub_tile<T, FULL, NWN, BM_>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, plus);
 }
 
 // Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
@@ -332,6 +333,14 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
                 else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
             }
         };
+        // skinny updates (the next panel's column block in the look-ahead driver, block rows in the sharded
+        // one): 128 x 128 tiles would leave most CUs idle, 64-row tiles double the workgroups
+        if (sizeof(T) == 8 && waves == 8 && aligned && m % 64 == 0 && n % BN == 0 && tm * tn <= h->num_cu / 2) {
+            hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 64>), dim3((m / 64) * tn), dim3(256), 0, h->stream, m, n, k,
+                               A, lda, B, ldb, C, ldc, m / 64, tn, 0, 0, plus);
+            LSX_HIP(hipGetLastError());
+            return LSX_OK;
+        }
         go(true, fm, fn, 0, 0);                 // interior
         go(false, tm - fm, tn, fm, 0);          // bottom strip (all columns)
         go(false, fm, tn - fn, 0, fn);          // right strip (complete tile rows only)

@@ -63,7 +63,8 @@ def test_device_fill_matches_host_generator(dev):
 
 # --------------------------------------------------------------------- MFMA update kernel
 @pytest.mark.parametrize("m,n,k", [(16, 16, 4), (128, 128, 128), (300, 200, 64), (1000, 130, 128),
-                                   (257, 513, 100), (64, 1, 64), (500, 7, 128), (129, 16, 3)])
+                                   (257, 513, 100), (64, 1, 64), (500, 7, 128), (129, 16, 3),
+                                   (1984, 128, 128), (64, 256, 16), (4032, 384, 128)])   # 64-row tiles
 def test_gemm_sub_fp64_against_numpy(dev, m, n, k):
     import torch
 
