@@ -158,7 +158,7 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     }
     struct Restore {  // the handle's stream is the update stream while this driver runs
         lsx_handle_t h; hipStream_t keep; int nt, rt;
-        ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; }
+        ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; h->panel_area_stride = 0; h->panel_area = 0; }
     } restore{h, caller, h->panel_nt, h->panel_rt};
     if (partitioned) {
         // every panel workgroup must be resident inside the panel's CU set: 128-row slices only
@@ -168,6 +168,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_start, 0));
         h->stream = main_s;
     }
+    // Exchange areas of the pipelined panel: two, used alternately, and cleared HERE on the main stream as
+    // soon as their panel has finished -- a clear in front of every panel launch sits on the chain.
+    size_t area = panel_pipe_area_bytes(h, n - k0);
+    if (2 * area > h->scratch_bytes) area = 0;
+    if (area) LSX_HIP(hipMemsetAsync(h->scratch, 0, 2 * area, main_s));
+    h->panel_area_stride = area;
+    h->panel_area = 0;
     // the side stream starts after everything already queued on the main stream (info memset, fills)
     LSX_HIP(hipEventRecord(h->ev_start, main_s));
     LSX_HIP(hipStreamWaitEvent(side, h->ev_start, 0));
@@ -223,10 +230,13 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
             // starts as soon as panel k and its block inverses are there.
             if (!partitioned) LSX_HIP(hipEventRecord(h->ev_panel, side));
             h->moves = h->moves_buf[(step + 1) & 1];
+            h->panel_area = (step + 1) & 1;
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
             next_valid = h->moves_valid;
         }
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+        // panel k is done with its exchange area; panel k+2 reuses it, behind ev_next below
+        if (area) LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
         h->moves = h->moves_buf[step & 1];   // panel k's list
         h->moves_valid = mv_valid;
         if (rest > jb2) {

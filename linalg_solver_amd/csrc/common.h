@@ -74,6 +74,10 @@ struct lsx_handle_s {
     int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
+    // look-ahead driver: > 0 = the pipelined panel alternates between two exchange areas this far apart in
+    // `scratch` and the DRIVER clears them (off the panel-to-panel chain); 0 = the launch clears its own
+    size_t panel_area_stride = 0;
+    int panel_area = 0;
     int num_cu = 256;
     // persistent device workspace (grown on demand, never shrunk)
     void *ws = nullptr;      // staging of caller matrices (host-buffer entry points)
@@ -150,6 +154,9 @@ int launch_rref_trace(lsx_handle_t h, int m, int n, int bar, double *R, int ldr,
 template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
                  int *d_info);
+// bytes of one exchange area of the pipelined panel for panels of up to m rows; 0 = this handle's panel
+// settings are not ones the pipelined kernel serves for every height <= m
+size_t panel_pipe_area_bytes(lsx_handle_t h, int m);
 template <typename T>
 int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, const int32_t *d_ipiv);
 // same interchanges from the gather list h->moves (written by the cooperative panel kernel)

@@ -559,17 +559,21 @@ static int panel_pipe_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp
     const size_t need = 256 + hdr_bytes + (size_t)2 * G * PC_COLS * sizeof(XGran);
     const size_t dbg_off = (need + 255) & ~(size_t)255;
     const size_t total = dbg_off + (h->panel_debug ? (size_t)G * 64 : 0);
-    if (total > h->scratch_bytes) {
-        set_error("panel_pipe: scratch too small (%zu > %zu)", total, h->scratch_bytes);
+    const bool driver_clears = h->panel_area_stride > 0 && !h->panel_debug;
+    const size_t base_off = driver_clears ? (size_t)h->panel_area * h->panel_area_stride : 0;
+    if (base_off + total > h->scratch_bytes || (driver_clears && need > h->panel_area_stride)) {
+        set_error("panel_pipe: scratch too small (%zu + %zu > %zu)", base_off, total, h->scratch_bytes);
         return LSX_ERR_INTERNAL;
     }
-    int *status = (int *)h->scratch;
-    char *hdr = (char *)h->scratch + 256;
-    XGran *xrow = (XGran *)((char *)h->scratch + 256 + hdr_bytes);
-    // status word, headers AND granules are zeroed before EVERY launch: epoch 0 never matches
-    LSX_HIP(hipMemsetAsync(h->scratch, 0, h->panel_debug ? total : need, h->stream));
+    char *base = (char *)h->scratch + base_off;
+    int *status = (int *)base;
+    char *hdr = base + 256;
+    XGran *xrow = (XGran *)(base + 256 + hdr_bytes);
+    // status word, headers AND granules are zero at EVERY launch (epoch 0 never matches): cleared here, or
+    // by the look-ahead driver beside the previous panel so that the memset is not on the panel-to-panel chain
+    if (!driver_clears) LSX_HIP(hipMemsetAsync(base, 0, h->panel_debug ? total : need, h->stream));
     if (h->panel_debug) {
-        unsigned long long *dbg = (unsigned long long *)((char *)h->scratch + dbg_off);
+        unsigned long long *dbg = (unsigned long long *)(base + dbg_off);
         hipLaunchKernelGGL((panel_pipe_kernel<T, RT, NT, KS, true>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
                            row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves);
     } else {
@@ -610,6 +614,18 @@ int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int 
     LSX_PP(8, 512, 1) LSX_PP(8, 512, 2) LSX_PP(8, 512, 4)
 #undef LSX_PP
     return 1;
+}
+
+size_t panel_pipe_area_bytes(lsx_handle_t h, int m) {
+    if (h->panel_mode != 3 || h->panel_debug || h->nb > PC_COLS) return 0;
+    if (h->panel_nt != 0 && h->panel_nt != 256 && h->panel_nt != 512) return 0;
+    if (!(h->panel_rt == 4 || (h->panel_rt == 8 && h->panel_nt == 512))) return 0;
+    if (m > 256 * (h->num_cu < 256 ? h->num_cu : 256)) return 0;
+    int G = (m + 127) / 128;        // 128-row slices above 4096 rows, never more than 64 slices below
+    if (G < 64) G = 64;
+    if (h->panel_nt == 256 && h->panel_rt == 4) G = (m + 63) / 64;
+    if (G > 256) G = 256;
+    return ((size_t)256 + (size_t)G * (2 * HDR_STRIDE + 2 * PC_COLS * sizeof(XGran)) + 255) & ~(size_t)255;
 }
 
 template int panel_pipelined<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);
