@@ -62,7 +62,8 @@ enum {
     LSX_PROF_TRSM = 2,   /* triangular inverse + U12 / block solves */
     LSX_PROF_GEMM = 3,   /* trailing update C -= A*B (MFMA) */
     LSX_PROF_OTHER = 4,
-    LSX_PROF_NBUCKETS = 5
+    LSX_PROF_GEMM_SKINNY = 5, /* the same update on 64-row tiles (few-tile shapes: the next panel's column block) */
+    LSX_PROF_NBUCKETS = 6
 };
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblsx.so")
 
-PROF_BUCKETS = {"panel": 0, "laswp": 1, "trsm": 2, "gemm": 3, "other": 4}
+PROF_BUCKETS = {"panel": 0, "laswp": 1, "trsm": 2, "gemm": 3, "other": 4, "gemm_skinny": 5}
 FILL_INT5, FILL_U11 = 0, 1
 PIVOT_FIRST, PIVOT_MAX = 0, 1
 
