@@ -218,11 +218,23 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         bool next_valid;
         {
             OnSide g(h, side);
-            LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
-            if (partitioned) LSX_HIP(hipEventRecord(h->ev_panel, side));   // panel k and its block inverses are done
-            if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
             h->moves = h->moves_buf[step & 1];
-            LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
+            // block inverses and the next block's interchanges in one launch when the main stream does not
+            // need the inverses earlier (it starts behind the chain anyway when the CUs are shared)
+            int fused = 1;
+            if (!partitioned) {
+                if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+                fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
+                if (fused < 0) return fused;
+            }
+            if (fused == 1) {
+                LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
+                if (partitioned) {
+                    LSX_HIP(hipEventRecord(h->ev_panel, side));   // panel k and its block inverses are done
+                    if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+                }
+                LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
+            }
             LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
             LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
             // Sharing the CUs, the big update would take the slots these small launches need (measured:

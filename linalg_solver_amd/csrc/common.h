@@ -168,6 +168,9 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
 // unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.
 template <typename T>
 int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv);
+// trtri(unit lower) + gather-list interchanges on a column block in one launch; 1 = not applicable
+template <typename T>
+int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0);
 template <typename T>
 int launch_trtri_both(lsx_handle_t h, int n, const T *LU, int lda, T *invL, T *invU);
 // B (jb x ncols) <- inv(Tm) * B in place; Tinv = inverses of Tm's 64x64 diagonal blocks.

@@ -136,9 +136,8 @@ int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, con
 // VW = elements per lane (1, or 16 bytes' worth: 2 in fp64, 4 in fp32): with VW > 1 ncols, lda, hole_at and hole_w
 // are counted in GROUPS of VW columns and A is read as such groups (the caller checks divisibility and alignment)
 template <typename T, int CW, int VW>
-__global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A_, int lda, int row0,
-                                                          const int2 *__restrict__ moves, int hole_at,
-                                                          int hole_w) {
+__device__ __forceinline__ void laswp_moves_body(int bx, int ncols, T *__restrict__ A_, int lda, int row0,
+                                                 const int2 *__restrict__ moves, int hole_at, int hole_w) {
     typedef T vw_t __attribute__((ext_vector_type(VW > 1 ? VW : 2)));
     typedef typename std::conditional<VW == 1, T, vw_t>::type vt;   // a 1-wide vector type ends up in scratch
     vt *__restrict__ A = (vt *)A_;
@@ -157,7 +156,7 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
     }
     __syncthreads();
     const int nmv = s_n;
-    const int c0 = blockIdx.x * CW;
+    const int c0 = bx * CW;
     const int tc = tid % CW, tr = tid / CW;
     constexpr int RP = 256 / CW;        // rows per pass
     constexpr int NP = 256 / RP;        // passes (max moves / RP)
@@ -179,6 +178,13 @@ __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restri
         const int d = tr + RP * i;
         if (cok && d < nmv) A[(size_t)(row0 + s_dst[d]) * lda + col] = v[i];
     }
+}
+
+template <typename T, int CW, int VW>
+__global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
+                                                          const int2 *__restrict__ moves, int hole_at,
+                                                          int hole_w) {
+    laswp_moves_body<T, CW, VW>(blockIdx.x, ncols, A, lda, row0, moves, hole_at, hole_w);
 }
 
 // all columns of an n-column matrix except the hole_w columns starting at hole_at, one launch
@@ -235,16 +241,16 @@ __device__ void lds_gemm_tile(int M, int N, int K, const T *A, int lda, const T 
 // lower = 0 / 1: that triangle; lower = 2: blockIdx.y = 0 inverts the lower, 1 the upper triangle, the
 // upper inverses going to Tinv + upper_off (both triangles of an LU in one launch)
 template <typename T>
-__global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T *__restrict__ Tm,
-                                                      int ldt, T *__restrict__ Tinv, size_t upper_off) {
+__device__ __forceinline__ void trtri64_body(int bx, int by, int lower, int jb, const T *__restrict__ Tm,
+                                             int ldt, T *__restrict__ Tinv, size_t upper_off) {
     __shared__ T X[TB * TLD];   // triangle in, inverse out
     __shared__ T W[32 * TLD];   // merge temporary
     if (lower == 2) {
-        lower = blockIdx.y == 0;
+        lower = by == 0;
         if (!lower) Tinv += upper_off;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b0 = blockIdx.x * TB;
+    const int b0 = bx * TB;
     // load (identity outside the matrix / outside the triangle)
     typedef T v2t __attribute__((ext_vector_type(2)));
     const bool fast = (b0 + TB <= jb) && ((size_t)Tm % 16 == 0) && (ldt % 2 == 0) && ((size_t)Tinv % 16 == 0);
@@ -335,14 +341,47 @@ __global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T
             v2t x;
             x[0] = X[(e / TB) * TLD + e % TB];
             x[1] = X[(e / TB) * TLD + e % TB + 1];
-            *(v2t *)(Tinv + (size_t)blockIdx.x * TB * TB + e) = x;
+            *(v2t *)(Tinv + (size_t)bx * TB * TB + e) = x;
         }
         return;
     }
     for (int e = tid; e < TB * TB; e += 256) {
         const int i = e / TB, j = e % TB;
-        Tinv[(size_t)blockIdx.x * TB * TB + e] = X[i * TLD + j];
+        Tinv[(size_t)bx * TB * TB + e] = X[i * TLD + j];
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T *__restrict__ Tm,
+                                                      int ldt, T *__restrict__ Tinv, size_t upper_off) {
+    trtri64_body<T>(blockIdx.x, blockIdx.y, lower, jb, Tm, ldt, Tinv, upper_off);
+}
+
+// Head of the look-ahead chain, one launch: the inverses of panel k's unit-lower diagonal blocks (workgroups
+// 0 .. ntri-1) and panel k's interchanges on the next panel's column block (the others) are independent.
+template <typename T, int CW, int VW>
+__global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const T *__restrict__ Tm, int ldt,
+                                                         T *__restrict__ Tinv, int ncols, T *__restrict__ A, int lda,
+                                                         int row0, const int2 *__restrict__ moves) {
+    if ((int)blockIdx.x < ntri)
+        trtri64_body<T>(blockIdx.x, 0, 1, jb, Tm, ldt, Tinv, 0);
+    else
+        laswp_moves_body<T, CW, VW>(blockIdx.x - ntri, ncols, A, lda, row0, moves, 0x7fffffff, 0);
+}
+
+// trtri(lower) of the jb x jb triangle at Tm  +  the gather-list interchanges on `ncols` columns at A.
+// Returns 1 when the shapes do not allow the 16-byte path (the caller then issues the two launches).
+template <typename T>
+int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int CW = 32 / VW;
+    if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
+    const int ntri = (jb + TB - 1) / TB;
+    ProfScope ps(h, LSX_PROF_TRSM);
+    hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
+                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)h->moves);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
 }
 
 template <typename T>
@@ -899,6 +938,7 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
     template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
     template int launch_laswp_moves_around<T>(lsx_handle_t, int, T *, int, int, int, int);        \
+    template int launch_chain_head<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int);  \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trtri_both<T>(lsx_handle_t, int, const T *, int, T *, T *);               \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
