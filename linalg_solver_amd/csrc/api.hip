@@ -277,6 +277,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     LSX_ARG(n >= 0 && lda >= n && A && d_ipiv);
     if (n == 0) return LSX_OK;
     const int nb = h->nb;
+    struct MfmaOnly { lsx_handle_t h; MfmaOnly(lsx_handle_t h_) : h(h_) { h->gemm_mfma_only = true; } ~MfmaOnly() { h->gemm_mfma_only = false; } } mfma_only(h);
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
                                   ((size_t)n / 32 + 2) * 5248 + 8192));
@@ -290,6 +291,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     // no longer hides the panel and the split update costs more than it saves; in fp32 the update is half
     // as long, so the break-even moves up (8192: -5 %, 10240: 0, 12288: +2.5 %, 16384: +6 %).
     int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 11264;
+    if (h->lookahead_min > 0) LOOKAHEAD_MIN = h->lookahead_min;                  // option (tests, tuning)
     if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) LOOKAHEAD_MIN = atoi(e);  // diagnostics
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
     if (h->lookahead && n >= LOOKAHEAD_MIN && h->kblock == 1) k_end = 0;
@@ -671,6 +673,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "lookahead")) {
         LSX_ARG(value >= 0 && value <= 2);
         h->lookahead = value;
+    } else if (!strcmp(key, "lookahead_min")) {
+        LSX_ARG(value >= 0);
+        h->lookahead_min = value;
     } else {
         set_error("unknown option '%s'", key);
         return LSX_ERR_ARG;
@@ -683,6 +688,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     if (!strcmp(key, "nb")) *value = h->nb;
     else if (!strcmp(key, "panel")) *value = h->panel_mode;
     else if (!strcmp(key, "lookahead")) *value = h->lookahead;
+    else if (!strcmp(key, "lookahead_min")) *value = h->lookahead_min;
     else if (!strcmp(key, "panel_rt")) *value = h->panel_rt;
     else if (!strcmp(key, "kblock")) *value = h->kblock;
     else if (!strcmp(key, "gemm_waves")) *value = h->gemm_waves;

@@ -68,12 +68,16 @@ struct lsx_handle_s {
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 3;  // 0 = per-column launches, 1 = cooperative, 2 = blocked (experimental), 3 = pipelined
     int lookahead = 1;   // 0: off; 1: panel k+1 on a high-priority side stream under the update of step k (n >= 7168: +5..12 %, bit-identical); 2: same, with the update and the panel on disjoint CU sets
+    int lookahead_min = 0; // smallest n the look-ahead driver takes (0 = measured default: 7168 fp64, 11264 fp32)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step
     int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
+    // set by the LU drivers: updates narrower than 16 columns also take the MFMA kernel, so that a column sees the
+    // same summation order whichever driver (sequential / look-ahead) splits the trailing matrix around it
+    bool gemm_mfma_only = false;
     // look-ahead driver: > 0 = the pipelined panel alternates between two exchange areas this far apart in
     // `scratch` and the DRIVER clears them (off the panel-to-panel chain); 0 = the launch clears its own
     size_t panel_area_stride = 0;

@@ -309,13 +309,14 @@ template <typename T>
 int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
                     T *C, int ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
+    const bool skinny = n < 16 && !h->gemm_mfma_only;
     const bool tiles64 = n >= 16 && sizeof(T) == 8 && (h->gemm_waves == 0 || h->gemm_waves == 8) && m % 64 == 0 &&
                          n % BN == 0 && k % BK == 0 && ((m + BM - 1) / BM) * (n / BN) <= h->num_cu / 2 &&
                          ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && lda % 2 == 0 &&
                          ldb % 2 == 0 && ldc % 2 == 0;
     ProfScope ps(h, tiles64 ? LSX_PROF_GEMM_SKINNY : LSX_PROF_GEMM, 2.0 * m * n * (double)k,
                  2.0 * sizeof(T) * m * (double)n);
-    if (n < 16) {
+    if (skinny) {
         hipLaunchKernelGGL(gemm_sub_skinny_kernel<T>, dim3((m + 3) / 4), dim3(256), 0, h->stream, m,
                            n, k, A, lda, B, ldb, C, ldc, plus);
     } else {

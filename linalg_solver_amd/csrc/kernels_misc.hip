@@ -375,6 +375,9 @@ template <typename T>
 int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int CW = 32 / VW;
+    // fp32: the fused launch gives wrong interchanges/inverses on aligned shapes (found by the ragged-size
+    // look-ahead test, cause not yet understood; the two separate launches are correct), so fp64 only for now
+    if (sizeof(T) != 8) return 1;
     if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
     const int ntri = (jb + TB - 1) / TB;
     ProfScope ps(h, LSX_PROF_TRSM);

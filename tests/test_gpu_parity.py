@@ -561,6 +561,36 @@ def test_full_size_lu_invariants(dev, n, kind):
         assert eye_err < 1e-7, eye_err
 
 
+@pytest.mark.parametrize("n", [129, 255, 300, 641, 1000, 1537, 2500, 3001])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
+    """The look-ahead driver (default above 7168 / 11264) forced onto small and odd orders: last panel narrower
+    than nb, odd leading dimension (no 16-byte paths), fewer tiles than CUs, partition fall-back.  Same bits as
+    the sequential driver, for every variant."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    A0 = torch.empty(n, n, dtype=tdt, device="cuda")
+    dev.fill_(A0, gen.U11, 40 + n)
+    outs = []
+    try:
+        dev.h.set_option("lookahead_min", 128)
+        for look in (0, 1, 2):
+            dev.h.set_option("lookahead", look)
+            LU = A0.clone()
+            ipiv, info = dev.getrf_(LU)
+            torch.cuda.synchronize()
+            assert int(info.item()) == 0
+            outs.append((LU, ipiv.clone()))
+    finally:
+        dev.h.set_option("lookahead", 1)
+        dev.h.set_option("lookahead_min", 0)
+    for LU, ipiv in outs[1:]:
+        assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
+
+
 def test_lookahead_variants_are_bit_identical_at_8192(dev):
     """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
     reorders launches: the factors must not change by a single bit."""
