@@ -243,8 +243,10 @@ __device__ void lds_gemm_tile(int M, int N, int K, const T *A, int lda, const T 
 template <typename T>
 __device__ __forceinline__ void trtri64_body(int bx, int by, int lower, int jb, const T *__restrict__ Tm,
                                              int ldt, T *__restrict__ Tinv, size_t upper_off) {
-    __shared__ T X[TB * TLD];   // triangle in, inverse out
-    __shared__ T W[32 * TLD];   // merge temporary
+    // 16-byte aligned: the fast paths move pairs of T, and inside the fused chain-head kernel the arrays follow
+    // other LDS variables
+    __shared__ __attribute__((aligned(16))) T X[TB * TLD];   // triangle in, inverse out
+    __shared__ __attribute__((aligned(16))) T W[32 * TLD];   // merge temporary
     if (lower == 2) {
         lower = by == 0;
         if (!lower) Tinv += upper_off;
@@ -375,8 +377,10 @@ template <typename T>
 int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int CW = 32 / VW;
-    // fp32: the fused launch gives wrong interchanges/inverses on aligned shapes (found by the ragged-size
-    // look-ahead test, cause not yet understood; the two separate launches are correct), so fp64 only for now
+    // fp32: the inverses come out wrong when trtri64_body runs inside this fused kernel (isolated with the
+    // ragged-size look-ahead test: interchanges through the fused kernel + inverses from their own launch are
+    // right, the reverse is wrong; 16-byte alignment of the LDS arrays was not it).  Cause not yet found, so
+    // fp32 keeps the two launches.
     if (sizeof(T) != 8) return 1;
     if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
     const int ntri = (jb + TB - 1) / TB;
