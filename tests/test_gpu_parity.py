@@ -591,6 +591,43 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
+@pytest.mark.parametrize("n,dtype", [(7168, "f64"), (7203, "f64"), (9000, "f64"), (11264, "f32"), (11331, "f32")])
+def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
+    """At and just above the orders where the look-ahead driver takes over by default (aligned and odd): same
+    bits as the sequential driver, and P A = L U to working precision."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    A0 = torch.empty(n, n, dtype=tdt, device="cuda")
+    dev.fill_(A0, gen.U11, 7)
+    assert dev.h.get_option("lookahead") == 1 and dev.h.get_option("lookahead_min") == 0
+    LU = A0.clone()
+    ipiv, info = dev.getrf_(LU)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    try:
+        dev.h.set_option("lookahead", 0)
+        LUs = A0.clone()
+        ipivs, infos = dev.getrf_(LUs)
+        torch.cuda.synchronize()
+    finally:
+        dev.h.set_option("lookahead", 1)
+    assert torch.equal(ipiv, ipivs) and torch.equal(LU, LUs)
+    piv = ipiv.cpu().numpy()
+    perm = np.arange(n)
+    for k in range(n):
+        p = piv[k]
+        if p != k:
+            perm[k], perm[p] = perm[p], perm[k]
+    L = torch.tril(LU, -1).double()
+    L.diagonal().fill_(1.0)
+    D = A0[torch.from_numpy(perm).cuda()].double() - L @ torch.triu(LU).double()
+    res = float(torch.linalg.norm(D) / torch.linalg.norm(A0.double()))
+    assert res < (1e-13 if dtype == "f64" else TOL32), res
+
+
 def test_lookahead_variants_are_bit_identical_at_8192(dev):
     """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
     reorders launches: the factors must not change by a single bit."""
