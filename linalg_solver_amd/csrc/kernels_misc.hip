@@ -375,13 +375,14 @@ __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const
 // Returns 1 when the shapes do not allow the 16-byte path (the caller then issues the two launches).
 template <typename T>
 int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
+    // fp64 only.  In fp32 the inverses come out wrong when trtri64_body runs inside this fused kernel (isolated
+    // with the ragged-size look-ahead test: interchanges through the fused kernel + inverses from their own
+    // launch are right, the reverse is wrong; neither 16-byte alignment of the LDS arrays nor the register
+    // footprint of the interchange half (8- instead of 16-byte lanes) was it).  Cause not yet found, so fp32
+    // keeps the two launches.
+    if (sizeof(T) != 8) return 1;
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int CW = 32 / VW;
-    // fp32: the inverses come out wrong when trtri64_body runs inside this fused kernel (isolated with the
-    // ragged-size look-ahead test: interchanges through the fused kernel + inverses from their own launch are
-    // right, the reverse is wrong; 16-byte alignment of the LDS arrays was not it).  Cause not yet found, so
-    // fp32 keeps the two launches.
-    if (sizeof(T) != 8) return 1;
     if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
     const int ntri = (jb + TB - 1) / TB;
     ProfScope ps(h, LSX_PROF_TRSM);
