@@ -223,7 +223,7 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{n}x{n} {args.dtype} LU with partial pivoting (getrf), u11 generator, resident in HBM",
                    "n": n, "nb": nb, "panel_mode": dev.h.get_option("panel"),
-                   "lookahead": (look_default if n >= (7168 if args.dtype == "f64" else 11264) else 0) if world == 1 else "depth-1, sharded driver",
+                   "lookahead": (look_default if n >= (7168 if args.dtype == "f64" else 10240) else 0) if world == 1 else "depth-1, sharded driver",
                    "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic columns x{world}, panel broadcast (RCCL)"},
         "roofline": {"bound": "mfma", "kernel": "gemm_sub_kernel<T,.,true,128> (trailing update C -= L21*U12, 128x128 tiles)",
                      "achieved": gemm_tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",

@@ -80,7 +80,8 @@ int lsx_synchronize(lsx_handle_t h);
 const char *lsx_last_error(void);
 /* Tunables: "nb" (panel width <= 128), "panel" (0 = per-column launches, 1 = cooperative,
  * 2 = blocked cooperative, 3 = pipelined cooperative [default]), "lookahead" (0 = sequential, 1 = next panel on a side stream under
- * the trailing update for n >= 7168 [default], 2 = same on disjoint CU sets; all bit-identical), "lookahead_min" (smallest n that takes the look-ahead driver;
+ * the trailing update for n >= 7168 (fp32: 10240) [default], 2 = the same on disjoint CU sets, 3 = 1; all
+ * bit-identical), "lookahead_min" (smallest n that takes the look-ahead driver;
  * 0 = the measured break-even), "kblock" (panels per trailing update),
  * "gemm_waves", "gemm_stagger", "panel_rt", "panel_nt", "trsv" (few-RHS solve: 1 = one cooperative launch
  * per direction [default], 0 = one launch per 128-row step).  Returns LSX_ERR_ARG for unknown keys. */

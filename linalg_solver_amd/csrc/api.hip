@@ -129,7 +129,7 @@ static int ensure_partition(lsx_handle_t h, int panel_cus) {
 // k0 = first column handled here (columns < k0 were factored by the sequential driver).
 template <typename T>
 static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv,
-                           int k0) {
+                           int k0, bool want_partition) {
     const int nb = h->nb;
     struct OnSide {  // launches inside this scope go to the given stream
         lsx_handle_t h; hipStream_t keep;
@@ -138,7 +138,7 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     };
     hipStream_t caller = h->stream;
     hipStream_t main_s = h->stream, side = h->side_stream;
-    bool partitioned = h->lookahead == 2;
+    bool partitioned = want_partition;
     int slice_rt = 4;
     if (partitioned) {
         // the panel's workgroups (128 rows each) all need a CU of their own inside the panel's CU
@@ -288,13 +288,17 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     // Look-ahead (panel k+1 on a side stream under the update of step k; bit-identical factors).  Measured
     // on MI355X with the pipelined panel, lookahead=1 against the sequential driver: n = 4096 -8 %,
     // 6144 +0.5 %, 7168 +5 %, 8192 +8 %, 10240..16384 +11..12 %, 20480 +10 %.  Below ~6500 the shorter update
-    // no longer hides the panel and the split update costs more than it saves; in fp32 the update is half
-    // as long, so the break-even moves up (8192: -5 %, 10240: 0, 12288: +2.5 %, 16384: +6 %).
-    int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 11264;
+    // no longer hides the panel and the split update costs more than it saves (fp32: see the variant choice below).
+    int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 10240;   // fp32: the update is half as long, break-even higher
     if (h->lookahead_min > 0) LOOKAHEAD_MIN = h->lookahead_min;                  // option (tests, tuning)
     if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) LOOKAHEAD_MIN = atoi(e);  // diagnostics
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
     if (h->lookahead && n >= LOOKAHEAD_MIN && h->kblock == 1) k_end = 0;
+    // lookahead = 1 / 3: both streams on all CUs; 2: on disjoint CU sets.  For ONE fp32 factorisation the
+    // partition is the faster variant between 7168 and ~14000 (8192: 20.8 ms against 22.4 sequential and 22.4
+    // shared), but factorisations issued back to back lose that again (23.6 against 22.6 ms per LU: measured,
+    // not yet explained), so the default stays with the shared-CU variant and its break-even.
+    const bool want_partition = h->lookahead == 2;
     const int W = nb * h->kblock;
     for (int k = 0; k < k_end; k += W) {
         const int w = (n - k < W) ? n - k : W;  // width of this super-block
@@ -343,7 +347,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
                                        A + (size_t)(k + w) * lda + k + w, lda));
         }
     }
-    if (k_end < n) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end);
+    if (k_end < n) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, want_partition);
     return LSX_OK;
 }
 
@@ -671,7 +675,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
-        LSX_ARG(value >= 0 && value <= 2);
+        LSX_ARG(value >= 0 && value <= 3);
         h->lookahead = value;
     } else if (!strcmp(key, "lookahead_min")) {
         LSX_ARG(value >= 0);

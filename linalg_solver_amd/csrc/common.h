@@ -67,8 +67,8 @@ struct lsx_handle_s {
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
     int panel_mode = 3;  // 0 = per-column launches, 1 = cooperative, 2 = blocked (experimental), 3 = pipelined
-    int lookahead = 1;   // 0: off; 1: panel k+1 on a high-priority side stream under the update of step k (n >= 7168: +5..12 %, bit-identical); 2: same, with the update and the panel on disjoint CU sets
-    int lookahead_min = 0; // smallest n the look-ahead driver takes (0 = measured default: 7168 fp64, 11264 fp32)
+    int lookahead = 1;   // 0: off; 1: panel k+1 on a high-priority side stream under the update of step k (fp64 n >= 7168, fp32 n >= 10240; bit-identical); 2: the variant with the update and the panel on disjoint CU sets; 3 = 1
+    int lookahead_min = 0; // smallest n the look-ahead driver takes (0 = measured default: 7168 fp64, 10240 fp32)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
     int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step

@@ -577,7 +577,7 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
     outs = []
     try:
         dev.h.set_option("lookahead_min", 128)
-        for look in (0, 1, 2):
+        for look in (0, 1, 2, 3):
             dev.h.set_option("lookahead", look)
             LU = A0.clone()
             ipiv, info = dev.getrf_(LU)
@@ -591,7 +591,7 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
-@pytest.mark.parametrize("n,dtype", [(7168, "f64"), (7203, "f64"), (9000, "f64"), (11264, "f32"), (11331, "f32")])
+@pytest.mark.parametrize("n,dtype", [(7168, "f64"), (7203, "f64"), (9000, "f64"), (10240, "f32"), (10307, "f32")])
 def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
     """At and just above the orders where the look-ahead driver takes over by default (aligned and odd): same
     bits as the sequential driver, and P A = L U to working precision."""
