@@ -215,6 +215,16 @@ int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, d
  * is_f32 = 0: v_mfma_f64_16x16x4_f64, 1: v_mfma_f32_16x16x4_f32. */
 int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops,
                        double *clock_mhz /* fp64 only: median in-kernel shader clock, may be NULL */);
+/* Diagnostics: cost of one round of the cross-CU record exchange under the panel factorisation
+ * (synchronous).  G participants = the workgroups with blockIdx % stride == 0 (stride 8: one XCD under
+ * round-robin dispatch); mode 0 = header all-gather, 1 = header all-gather + the 128-granule row of a
+ * rotating winner, 2 = ping-pong between two participants; write_through 1 = `sc1` stores (device scope),
+ * 0 = plain stores (XCD scope: only meaningful when xcc_ids come back all equal).  xcc_ids[G] may be NULL. */
+int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_through, int epochs,
+                        double *us_per_epoch, int *xcc_ids, int *nfail);
+/* Diagnostics: launch nblocks workgroups on a stream created with the given CU mask (nwords = 0: the handle's
+ * stream) and report where each landed: out[2 b] = XCC id, out[2 b + 1] = HW_ID register.  Synchronous. */
+int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out);
 /* Copy a piece of the handle's device scratch to the host (stamped diagnostic builds). */
 int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes);
 

@@ -69,6 +69,8 @@ _SIGS = {
     "lsx_fill_f32_dev": [_vp, _i, _u64, _i, _i, _vp, _i, _i, _i],
     "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp, _dp],
     "lsx_diag_read_scratch": [_vp, C.c_size_t, _vp, C.c_size_t],
+    "lsx_diag_xchg_probe": [_vp, _i, _i, _i, _i, _i, _dp, _ip, _ip],
+    "lsx_diag_cu_mask_probe": [_vp, C.POINTER(C.c_uint32), _i, _i, C.POINTER(C.c_uint32)],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],
     "lsx_prof_read": [_vp, _i, _dp, C.POINTER(C.c_longlong), _dp, _dp],
@@ -174,6 +176,28 @@ class Handle:
         check(self.lib.lsx_diag_mfma_peak(self._h, 1 if is_f32 else 0, iters, blocks_per_cu, C.byref(t),
                                           C.byref(c)))
         return t.value, c.value
+
+    def xchg_probe(self, mode: int, G: int, stride: int, write_through: bool, epochs: int = 2000):
+        """(us per exchange round, XCC id of every participant, failures) -- see lsx_diag_xchg_probe."""
+        us, nf = C.c_double(0), C.c_int32(0)
+        ids = (C.c_int32 * G)()
+        check(self.lib.lsx_diag_xchg_probe(self._h, mode, G, stride, 1 if write_through else 0, epochs,
+                                           C.byref(us), ids, C.byref(nf)), "diag_xchg_probe")
+        return us.value, list(ids), nf.value
+
+    def cu_mask_probe(self, mask_bits, nblocks: int = 2048):
+        """Where the workgroups of a CU-masked stream land: list of (xcc, hw_id) per block; mask_bits = iterable
+        of enabled bit positions (None: the handle's own stream)."""
+        out = (C.c_uint32 * (2 * nblocks))()
+        if mask_bits is None:
+            check(self.lib.lsx_diag_cu_mask_probe(self._h, None, 0, nblocks, out), "cu_mask_probe")
+        else:
+            words = [0] * 8
+            for b in mask_bits:
+                words[b // 32] |= 1 << (b % 32)
+            arr = (C.c_uint32 * 8)(*words)
+            check(self.lib.lsx_diag_cu_mask_probe(self._h, arr, 8, nblocks, out), "cu_mask_probe")
+        return [(out[2 * i], out[2 * i + 1]) for i in range(nblocks)]
 
     def read_scratch(self, offset: int, nbytes: int) -> bytes:
         buf = C.create_string_buffer(nbytes)

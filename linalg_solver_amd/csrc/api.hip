@@ -157,9 +157,12 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         }
     }
     struct Restore {  // the handle's stream is the update stream while this driver runs
-        lsx_handle_t h; hipStream_t keep; int nt, rt;
-        ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; h->panel_area_stride = 0; h->panel_area = 0; }
-    } restore{h, caller, h->panel_nt, h->panel_rt};
+        lsx_handle_t h; hipStream_t keep; int nt, rt, mode;
+        ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; h->panel_mode = mode; h->panel_area_stride = 0; h->panel_area = 0; }
+    } restore{h, caller, h->panel_nt, h->panel_rt, h->panel_mode};
+    // this schedule shares the CUs between the panel and the update: the XCD-scope panel (which fills an XCD) has
+    // its own driver, getrf_lookahead_x; here it would stall every launch beside it
+    if (h->panel_mode == 4) h->panel_mode = 3;
     if (partitioned) {
         // every panel workgroup must be resident inside the panel's CU set: 128-row slices only
         h->panel_nt = 512;
@@ -271,6 +274,121 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     return LSX_OK;
 }
 
+// ---------------------------------------------------------------- look-ahead LU driver, XCD-scope panel
+// The panel of step k+1 (kernels_panel_x.hip) fills every CU of ONE XCD while it runs, and the hardware deals an
+// eighth of EVERY kernel's workgroups to that XCD whatever the stream or CU mask (measured: lsx_diag_cu_mask_probe),
+// so a kernel launched beside a running panel cannot finish before the panel does.  The schedule is built on that:
+//   side:  [chain head k: block inverses + panel k's interchanges on the next panel's columns] -> record HEAD
+//          -> U12 and update of the next panel's column block -> gate -> panel k+1
+//   main:  wait HEAD -> clear panel k's exchange area -> interchanges, U12 and update of all other columns, the
+//          update as ONE work-queue kernel whose workgroups on the panel's XCD leave at once and count themselves;
+//          the gate in front of panel k+1 waits for that count, i.e. until the update no longer needs the XCD
+//   nothing else is launched while a panel runs: the interchanges on the columns LEFT of the panels are applied
+//   for the whole factorisation by one launch at the end (one gather list per panel is kept).
+// Factors and pivots are bit-identical to the other drivers (same kernels per element, tests).
+template <typename T>
+static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv, int k0) {
+    const int nb = h->nb;
+    const int nsteps = (n - k0 + nb - 1) / nb;
+    hipStream_t main_s = h->stream, side = h->side_stream;
+    struct OnSide {
+        lsx_handle_t h; hipStream_t keep;
+        OnSide(lsx_handle_t h_, hipStream_t s) : h(h_), keep(h_->stream) { h->stream = s; }
+        ~OnSide() { h->stream = keep; }
+    };
+    const size_t area = panel_x_area_bytes(h, n - k0, sizeof(T));
+    const size_t words = pad256(256 + (size_t)nsteps * sizeof(int)) + (size_t)nsteps * 8 * sizeof(int);
+    if (area == 0 || 2 * area + words > h->scratch_bytes) { set_error("getrf_lookahead_x: scratch"); return LSX_ERR_INTERNAL; }
+    LSX_TRY(grow(&h->moves_all, &h->moves_all_bytes, (size_t)nsteps * 2048));
+    struct Restore {
+        lsx_handle_t h; hipStream_t keep;
+        ~Restore() {
+            h->stream = keep; h->panel_area_stride = 0; h->panel_area = 0; h->moves = h->moves_buf[0];
+            h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr;
+            h->panel_xcc_word = nullptr;
+        }
+    } restore{h, main_s};
+    char *wbase = (char *)h->scratch + 2 * area;
+    int *xcc_word = (int *)wbase;                    // 1 + XCC id of the panel's XCD (blocks = 0 mod 8 land on XCC 0)
+    int *pass = (int *)(wbase + 256);                // per step: update workgroups that left the panel's XCD
+    int *counters = (int *)(wbase + pad256(256 + (size_t)nsteps * sizeof(int)));
+    LSX_HIP(hipMemsetAsync(h->scratch, 0, 2 * area + words, main_s));
+    LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)xcc_word, 1, 1, main_s));
+    h->panel_area_stride = area;
+    h->panel_xcc_word = xcc_word;
+    LSX_HIP(hipEventRecord(h->ev_start, main_s));
+    LSX_HIP(hipStreamWaitEvent(side, h->ev_start, 0));
+    auto list = [&](int s) { return (void *)((char *)h->moves_all + (size_t)s * 2048); };
+    T *Tinv2[2] = {Tinv, Tinv + (size_t)((nb + 63) / 64) * 4096};
+    {
+        OnSide g(h, side);
+        h->moves = list(0);
+        h->panel_area = 0;
+        LSX_TRY(launch_panel<T>(h, n - k0, (n - k0) < nb ? (n - k0) : nb, A + (size_t)k0 * lda + k0, lda, k0, d_ipiv + k0, d_info));
+        if (!h->moves_valid) { set_error("getrf_lookahead_x: panel without a gather list"); return LSX_ERR_INTERNAL; }
+    }
+    int step = 0;
+    for (int k = k0; k < n; k += nb, ++step) {
+        const int jb = (n - k < nb) ? n - k : nb;
+        const int rest = n - k - jb;
+        if (rest <= 0) break;
+        T *Akk = A + (size_t)k * lda + k;
+        T *Ti = Tinv2[step & 1];
+        T *A12 = A + (size_t)k * lda + k + jb;
+        T *L21 = A + (size_t)(k + jb) * lda + k;
+        T *A22 = A + (size_t)(k + jb) * lda + k + jb;
+        const int jb2 = rest < nb ? rest : nb;  // width of the next panel
+        {
+            OnSide g(h, side);
+            if (step > 0) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));   // update k-1 wrote the next panel's columns
+            h->moves = list(step);
+            h->moves_valid = true;
+            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
+            if (fused < 0) return fused;
+            if (fused == 1) {
+                LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
+                LSX_TRY(launch_laswp_moves<T>(h, jb2, A + k + jb, lda, k));
+            }
+            LSX_HIP(hipEventRecord(h->ev_panel, side));   // HEAD: block inverses of panel k are there
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
+            LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
+        }
+        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
+        int queued = 0;
+        if (rest > jb2) {
+            h->moves = list(step);
+            h->moves_valid = true;
+            LSX_TRY(launch_laswp_moves<T>(h, rest - jb2, A + k + jb + jb2, lda, k));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest - jb2, Akk, lda, Ti, A12 + jb2, lda));
+            h->gemm_queue = 1;
+            h->gemm_counters = counters + 8 * step;
+            h->gemm_counter_sets = 1;
+            h->gemm_counter_set = 0;
+            h->gemm_avoid_word = xcc_word;
+            h->gemm_pass_word = pass + step;
+            const int rq = launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda);
+            queued = h->gemm_queue_used;
+            h->gemm_queue = 0;
+            h->gemm_counters = nullptr;
+            LSX_TRY(rq);
+        }
+        LSX_HIP(hipEventRecord(h->ev_next, main_s));
+        {
+            OnSide g(h, side);
+            if (queued) LSX_TRY(launch_gate(h, pass + step, 2 * h->num_cu / 8));
+            h->moves = list(step + 1);
+            h->panel_area = (step + 1) & 1;
+            LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
+            if (!h->moves_valid) { set_error("getrf_lookahead_x: panel without a gather list"); return LSX_ERR_INTERNAL; }
+        }
+    }
+    // the last panel is factored; every panel's interchanges on the columns left of it
+    LSX_HIP(hipEventRecord(h->ev_panel, side));
+    LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+    return launch_laswp_left_all<T>(h, A, lda, k0, nb, nsteps, h->moves_all);
+}
+
 // ---------------------------------------------------------------- blocked LU driver
 template <typename T>
 static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info) {
@@ -280,7 +398,8 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     struct MfmaOnly { lsx_handle_t h; MfmaOnly(lsx_handle_t h_) : h(h_) { h->gemm_mfma_only = true; } ~MfmaOnly() { h->gemm_mfma_only = false; } } mfma_only(h);
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
-                                  ((size_t)n / 32 + 2) * 5248 + 8192));
+                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 2 * panel_x_area_bytes(h, n, sizeof(T)) + 16384 +
+                                  ((size_t)n / 16 + 2) * 40));
     const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * sizeof(T))));   // x2: the look-ahead driver alternates
     T *Tinv = (T *)h->ws2;
@@ -290,6 +409,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     // 6144 +0.5 %, 7168 +5 %, 8192 +8 %, 10240..16384 +11..12 %, 20480 +10 %.  Below ~6500 the shorter update
     // no longer hides the panel and the split update costs more than it saves (fp32: see the variant choice below).
     int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 10240;   // fp32: the update is half as long, break-even higher
+    if (h->panel_mode == 4) LOOKAHEAD_MIN = sizeof(T) == 8 ? 3072 : 4096;   // XCD-scope panel and its own schedule
     if (h->lookahead_min > 0) LOOKAHEAD_MIN = h->lookahead_min;                  // option (tests, tuning)
     if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) LOOKAHEAD_MIN = atoi(e);  // diagnostics
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
@@ -347,7 +467,14 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
                                        A + (size_t)(k + w) * lda + k + w, lda));
         }
     }
-    if (k_end < n) return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, want_partition);
+    if (k_end < n) {
+        // XCD-scope panel (panel = 4): its own schedule, for the part of the matrix whose panels one XCD holds
+        const int xrows = 32 * 64 * (sizeof(T) == 8 ? 4 : 8);
+        if (h->panel_mode == 4 && !want_partition && !h->panel_debug && nb % 32 == 0 && k_end % 32 == 0 && n - k_end <= xrows &&
+            panel_x_area_bytes(h, n - k_end, sizeof(T)) > 0)
+            return getrf_lookahead_x<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end);
+        return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, want_partition);
+    }
     return LSX_OK;
 }
 
@@ -614,6 +741,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->moves_buf[0]) (void)hipFree(h->moves_buf[0]);
+    if (h->moves_all) (void)hipFree(h->moves_all);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -652,7 +780,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
         LSX_ARG(value >= 16 && value <= 128 && value % 16 == 0);
         h->nb = value;
     } else if (!strcmp(key, "panel")) {
-        LSX_ARG(value >= 0 && value <= 3);
+        LSX_ARG(value >= 0 && value <= 4);
         h->panel_mode = value;
     } else if (!strcmp(key, "trsv")) {
         LSX_ARG(value == 0 || value == 1);
@@ -672,6 +800,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_nt")) {
         LSX_ARG(value == 0 || value == 256 || value == 512 || value == 1024);
         h->panel_nt = value;
+    } else if (!strcmp(key, "panel_xcd")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->panel_xcd = value;
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
@@ -699,6 +830,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "gemm_stagger")) *value = h->gemm_stagger;
     else if (!strcmp(key, "trsv")) *value = h->trsv_mode;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
+    else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
     return LSX_OK;
@@ -987,6 +1119,18 @@ int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu,
                        double *clock_mhz) {
     LSX_ARG(h && tflops && iters > 0 && blocks_per_cu >= 1 && blocks_per_cu <= 8);
     return diag_mfma_peak(h, is_f32, iters, blocks_per_cu, tflops, clock_mhz);
+}
+
+int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_through, int epochs,
+                        double *us_per_epoch, int *xcc_ids, int *nfail) {
+    LSX_ARG(h && us_per_epoch && nfail && G >= 2 && G <= 64 && (stride == 1 || stride == 8) && epochs >= 1);
+    LSX_ARG(mode >= 0 && mode <= 2 && (G - 1) * stride + 1 <= 8 * h->num_cu);
+    return diag_xchg_probe(h, mode, G, stride, write_through, epochs, us_per_epoch, xcc_ids, nfail);
+}
+
+int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out) {
+    LSX_ARG(h && out && nblocks >= 1 && nwords >= 0 && (nwords == 0 || mask_words));
+    return diag_cu_mask_probe(h, mask_words, nwords, nblocks, out);
 }
 
 // ---- measurement

@@ -66,7 +66,7 @@ struct lsx_handle_s {
     // tunables
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb
-    int panel_mode = 3;  // 0 = per-column launches, 1 = cooperative, 2 = blocked (experimental), 3 = pipelined
+    int panel_mode = 4;  // 0 = per-column launches, 1 = cooperative, 2 = blocked (experimental), 3 = pipelined (device-scope exchange), 4 = XCD-scope exchange on one XCD (taller panels than an XCD holds: 3)
     int lookahead = 1;   // 0: off; 1: panel k+1 on a high-priority side stream under the update of step k (fp64 n >= 7168, fp32 n >= 10240; bit-identical); 2: the variant with the update and the panel on disjoint CU sets; 3 = 1
     int lookahead_min = 0; // smallest n the look-ahead driver takes (0 = measured default: 7168 fp64, 10240 fp32)
     int panel_rt = 4;     // rows per thread in the cooperative panel
@@ -74,6 +74,17 @@ struct lsx_handle_s {
     int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step
     int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
+    // trailing update through a work queue (look-ahead driver with the XCD-scope panel): see kernels_gemm.hip
+    int gemm_queue = 0;           // 1: interior tiles are handed out by per-XCD counters
+    const int *gemm_avoid_word = nullptr;  // device word: 1 + XCC id whose workgroups take no tiles (the panel's XCD)
+    int *panel_xcc_word = nullptr;         // where the XCD-scope panel kernel records 1 + its XCC id
+    int *gemm_counters = nullptr; // gemm_counter_sets x 8 ints in scratch, zeroed by the driver
+    int gemm_counter_sets = 0, gemm_counter_set = 0;
+    int *gemm_pass_word = nullptr;   // incremented by every workgroup that leaves because it sits on the avoided XCD
+    int gemm_queue_used = 0;         // set by the last launch_gemm_*: 1 = its interior went through the queue
+    void *moves_all = nullptr;       // look-ahead driver with the XCD-scope panel: one gather list per panel
+    size_t moves_all_bytes = 0;
+    int panel_xcd = 0;    // 1: pipelined panel with the exchange at XCD scope (<= 32 workgroups on one XCD)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     // set by the LU drivers: updates narrower than 16 columns also take the MFMA kernel, so that a column sees the
     // same summation order whichever driver (sequential / look-ahead) splits the trailing matrix around it
@@ -161,11 +172,15 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
 // bytes of one exchange area of the pipelined panel for panels of up to m rows; 0 = this handle's panel
 // settings are not ones the pipelined kernel serves for every height <= m
 size_t panel_pipe_area_bytes(lsx_handle_t h, int m);
+size_t panel_x_area_bytes(lsx_handle_t h, int m, size_t elem);
 template <typename T>
 int launch_laswp(lsx_handle_t h, int ncols, T *A, int lda, int row0, int jb, const int32_t *d_ipiv);
 // same interchanges from the gather list h->moves (written by the cooperative panel kernel)
 template <typename T>
 int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
+template <typename T>
+int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nsteps, const void *lists);
+int launch_gate(lsx_handle_t h, const int *word, int target);
 template <typename T>
 int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, int hole_at, int hole_w);
 // Tinv (ceil(jb/64) blocks of 64x64) <- inverses of the 64x64 diagonal blocks of the
@@ -202,6 +217,9 @@ template <typename T>
 int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B, int ldb, T *X, T *inv64L,
                      T *inv64U, T *inv128L, T *inv128U);
 int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz);
+int diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, unsigned *out_host);
+int diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int wt, int epochs, double *us_per_epoch,
+                    int *xcc_ids, int *nfail);
 template <typename T>
 int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int ldd);
 

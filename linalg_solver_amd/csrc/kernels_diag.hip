@@ -105,3 +105,173 @@ int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, dou
 }
 
 }  // namespace lsx
+
+// ---------------------------------------------------------------------------------------------
+// Cross-CU exchange probe: what one "everybody publishes a 16-byte record, everybody reads all of
+// them" round costs, by store policy and placement.  This is the primitive under the panel
+// factorisation's per-column pivot exchange (kernels_panel_pipe.hip), measured on its own so the
+// floor of the column chain is a number.
+//   participants: blocks with blockIdx.x % stride == 0 (stride 8 = one XCD under round-robin dispatch)
+//   mode 0: all-gather of headers only        (lane q of wave 0 polls participant q's header)
+//   mode 1: header all-gather, then the 128-granule row of a rotating "winner" (two dependent reads)
+//   mode 2: ping-pong between participants 0 and 1 (one-way latency = time / 2 / epochs)
+// wt = 1: write-through (`sc1`) stores, the device-scope form; wt = 0: plain stores that stay in the
+// XCD's L2 (valid only when every participant sits on one XCD).  Loads are always `sc1` (bypass L1).
+// out[g] = {100 MHz ticks, xcc id, failures}.
+#include "panel_xchg.h"
+
+namespace lsx {
+
+template <bool WT>
+__device__ __forceinline__ void probe_store(__amdgpu_buffer_rsrc_t r, u4 v, int off) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, WT ? 16 : 0);
+}
+
+template <bool WT>
+__global__ __launch_bounds__(256) void xchg_probe_kernel(int mode, int stride, int epochs, char *area,
+                                                         unsigned long long *out) {
+    if (blockIdx.x % stride) return;
+    const int G = (gridDim.x + stride - 1) / stride, g = blockIdx.x / stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    __amdgpu_buffer_rsrc_t r_hdr = __builtin_amdgcn_make_buffer_rsrc(area, 0, G * HDR_STRIDE, 0x00020000);
+    char *rows = area + (size_t)G * HDR_STRIDE;
+    __amdgpu_buffer_rsrc_t r_row = __builtin_amdgcn_make_buffer_rsrc(rows, 0, G * 128 * 16, 0x00020000);
+    int fails = 0;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (mode == 2) {
+        if (g < 2 && wave == 0) {
+            for (int e = 1; e <= epochs; ++e) {
+                // g = 0 sends, g = 1 answers
+                if (g == 0) {
+                    if (lane == 0) probe_store<WT>(r_hdr, u4{0u, 0u, 0u, (unsigned)e}, 0);
+                    int spins = 0;
+                    for (;;) {
+                        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, HDR_STRIDE, opaque_zero(), 16);
+                        if (__builtin_amdgcn_readfirstlane((int)v.w) == e) break;
+                        if (++spins > SPIN_LIMIT) { ++fails; break; }
+                    }
+                } else {
+                    int spins = 0;
+                    for (;;) {
+                        const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, 0, opaque_zero(), 16);
+                        if (__builtin_amdgcn_readfirstlane((int)v.w) == e) break;
+                        if (++spins > SPIN_LIMIT) { ++fails; break; }
+                    }
+                    if (lane == 0) probe_store<WT>(r_hdr, u4{0u, 0u, 0u, (unsigned)e}, HDR_STRIDE);
+                }
+                if (fails) break;
+            }
+        }
+    } else {
+        for (int e = 1; e <= epochs && !fails; ++e) {
+            if (wave == 0) {
+                if (lane == 0) probe_store<WT>(r_hdr, u4{(unsigned)g, 0u, 0u, (unsigned)e}, g * HDR_STRIDE);
+            }
+            if (mode == 1 && wave < 2) {   // every participant publishes its candidate row: 128 granules
+                const int c = tid;         // waves 0 and 1: one granule per lane
+                probe_store<WT>(r_row, u4{(unsigned)c, (unsigned)g, (unsigned)e, 0u}, (g * 128 + c) * 16);
+            }
+            if (wave == 0) {
+                int spins = 0;
+                bool pend = lane < G;
+                while (__any(pend)) {
+                    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r_hdr, (lane < G ? lane : 0) * HDR_STRIDE,
+                                                                       opaque_zero(), 16);
+                    // headers of epoch e or later count (a fast participant may already be one ahead)
+                    if ((int)v.w >= e) pend = false;
+                    if (++spins > SPIN_LIMIT) { ++fails; break; }
+                }
+                if (mode == 1 && !fails) {
+                    const int win = (e * 7) % G;
+                    int spins2 = 0;
+                    for (;;) {
+                        const int oz = opaque_zero();
+                        const u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(r_row, (win * 128 + lane) * 16, oz, 16);
+                        const u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(r_row, (win * 128 + lane + 64) * 16, oz, 16);
+                        if (!__any(((int)v0.z < e) | ((int)v1.z < e))) {
+                            if (v0.x != (unsigned)lane || v1.x != (unsigned)(lane + 64) || v0.y != (unsigned)win) ++fails;
+                            break;
+                        }
+                        if (++spins2 > SPIN_LIMIT) { ++fails; break; }
+                    }
+                }
+            }
+            // the other waves wait for wave 0 as the panel's bulk waves do (one barrier per column)
+            __syncthreads();
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {
+        out[3 * g] = t1 - t0;
+        out[3 * g + 1] = xcc;
+        out[3 * g + 2] = (unsigned long long)fails;
+    }
+}
+
+// us_per_epoch: mean over participants; xcc_ids[G] (may be null); failures through *nfail
+int diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int wt, int epochs, double *us_per_epoch,
+                    int *xcc_ids, int *nfail) {
+    const size_t body = ((size_t)G * HDR_STRIDE + (size_t)G * 128 * 16 + 255) & ~(size_t)255;
+    const size_t need = body + (size_t)G * 24 + 256;
+    if (need > h->scratch_bytes) { set_error("xchg_probe: scratch too small"); return LSX_ERR_INTERNAL; }
+    char *area = (char *)h->scratch;
+    unsigned long long *out = (unsigned long long *)(area + body);
+    std::vector<unsigned long long> ho(3 * (size_t)G);
+    for (int rep = 0; rep < 2; ++rep) {
+        LSX_HIP(hipMemsetAsync(area, 0, need, h->stream));
+        const int grid = (G - 1) * stride + 1;
+        if (wt) hipLaunchKernelGGL(xchg_probe_kernel<true>, dim3(grid), dim3(256), 0, h->stream, mode, stride, epochs, area, out);
+        else hipLaunchKernelGGL(xchg_probe_kernel<false>, dim3(grid), dim3(256), 0, h->stream, mode, stride, epochs, area, out);
+        LSX_HIP(hipGetLastError());
+        LSX_HIP(hipStreamSynchronize(h->stream));
+    }
+    LSX_HIP(hipMemcpy(ho.data(), out, ho.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double s = 0;
+    int f = 0;
+    const int cnt = mode == 2 ? 2 : G;
+    for (int g = 0; g < cnt; ++g) s += (double)ho[3 * g] / 100.0 / epochs;
+    for (int g = 0; g < G; ++g) {
+        if (xcc_ids) xcc_ids[g] = (int)ho[3 * g + 1];
+        f += (int)ho[3 * g + 2];
+    }
+    *us_per_epoch = s / cnt;
+    *nfail = f;
+    return LSX_OK;
+}
+
+}  // namespace lsx
+
+// ---------------------------------------------------------------------------------------------
+// Where do the workgroups of a stream created with hipExtStreamCreateWithCUMask land?  The look-ahead driver
+// wants one stream whose kernels never need the XCD that the panel factorisation occupies; which mask bits
+// belong to which XCD is not documented, so it is measured: every workgroup records its XCC id and HW_ID.
+namespace lsx {
+
+__global__ __launch_bounds__(256) void where_kernel(unsigned *out, int spin) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    for (int i = 0; i < spin; ++i) __builtin_amdgcn_s_sleep(64);   // keep the workgroup resident so the grid spreads
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
+}
+
+// mask_words: the CU mask (ncu bits); out: per block {xcc, hw_id}
+int diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, unsigned *out_host) {
+    if ((size_t)nblocks * 8 > h->scratch_bytes) { set_error("cu_mask_probe: scratch too small"); return LSX_ERR_INTERNAL; }
+    hipStream_t st = nullptr;
+    if (nwords > 0) LSX_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)nwords, mask_words));
+    else st = h->stream;
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(where_kernel, dim3(nblocks), dim3(256), 0, st, (unsigned *)h->scratch, 20);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(out_host, h->scratch, (size_t)nblocks * 8, hipMemcpyDeviceToHost);
+    if (nwords > 0) (void)hipStreamDestroy(st);
+    if (e != hipSuccess) { set_error("cu_mask_probe: %s", hipGetErrorString(e)); return LSX_ERR_HIP; }
+    return LSX_OK;
+}
+
+}  // namespace lsx

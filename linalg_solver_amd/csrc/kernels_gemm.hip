@@ -274,6 +274,58 @@ __global__ __launch_bounds__(BM_ * NWN, (BM_ == 64) ? 2 : (sizeof(T) == 4 && NWN
     gemm_sub_tile<T, FULL, NWN, BM_>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, plus);
 }
 
+// The same interior tiles handed out by a work queue instead of one workgroup per tile: the look-ahead driver
+// runs the next panel on ONE XCD while this update runs (kernels_panel_x.hip), so an eighth of the chip joins
+// late or not at all and a static tile -> workgroup map would leave that eighth's tiles for the end.
+//   grid = resident workgroups (2 per CU); a workgroup whose XCC id is `avoid_xcc` leaves at once (the panel's
+//   XCD: its CUs stay free for the panel's workgroups whatever the dispatch order of the two kernels);
+//   queues: one counter per active XCD over a contiguous share of the tile sequence (the XCD-aware band order
+//   above, so an XCD's workgroups walk compact bands and L21 / U12 slabs stay in its L2), own share first,
+//   then the others' (work stealing), so the tail is balanced.
+// The XCC id is read from the hardware register, never inferred from blockIdx.
+template <typename T, int NWN>
+__global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_queue_kernel(
+    int M, int N, int K, const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb, T *__restrict__ C,
+    int ldc, int tiles_m, int tiles_n, int plus, int *__restrict__ counters, const int *__restrict__ avoid_word,
+    int *__restrict__ pass_word) {
+    __shared__ T As[2][BK / 2][ASlab<T, BM>::PAIR];
+    __shared__ T Bs[2][BK][BN + LPAD];
+    __shared__ int s_tile;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    // *avoid_word = 1 + XCC id of the last XCD-scope panel launch (0: none yet); written by that kernel
+    const int avoid_xcc = avoid_word ? __hip_atomic_load(avoid_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - 1 : -1;
+    if ((int)xcc == avoid_xcc) {
+        // seen by the gate in front of the panel launch (kernels_misc.hip: gate_kernel)
+        if (pass_word && threadIdx.x == 0) __hip_atomic_fetch_add(pass_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int nx = avoid_xcc >= 0 ? 7 : 8;
+    const int rank = (avoid_xcc >= 0 && (int)xcc > avoid_xcc) ? (int)xcc - 1 : (int)xcc;
+    const int nwg = tiles_m * tiles_n;
+    const int share = (nwg + nx - 1) / nx;
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n;
+    for (int q = 0; q < nx; ++q) {
+        const int owner = (rank + q) % nx;
+        const int lo = owner * share, hi = min(nwg, lo + share);
+        for (;;) {
+            if (threadIdx.x == 0) s_tile = lo + atomicAdd(&counters[owner], 1);
+            __syncthreads();
+            const int bid = s_tile;
+            __syncthreads();   // s_tile is rewritten next trip
+            if (bid >= hi) break;
+            const int group_id = bid / per_group;
+            const int first_m = group_id * GROUP;
+            const int gsize = min(tiles_m - first_m, GROUP);
+            const int tile_m = first_m + (bid % per_group) % gsize;
+            const int tile_n = (bid % per_group) / gsize;
+            gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus);
+            __syncthreads();   // the tile's last LDS reads are done before the next tile's first slab is stored
+        }
+    }
+}
+
 // Small / skinny problems (n < 16, e.g. a single right-hand side): plain FMA,
 // one thread per C element, A row and B column streamed from L2.
 template <typename T>
@@ -309,8 +361,9 @@ template <typename T>
 int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, int lda, const T *B, int ldb,
                     T *C, int ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
+    h->gemm_queue_used = 0;
     const bool skinny = n < 16 && !h->gemm_mfma_only;
-    const bool tiles64 = n >= 16 && sizeof(T) == 8 && (h->gemm_waves == 0 || h->gemm_waves == 8) && m % 64 == 0 &&
+    const bool tiles64 = !h->gemm_queue && n >= 16 && sizeof(T) == 8 && (h->gemm_waves == 0 || h->gemm_waves == 8) && m % 64 == 0 &&
                          n % BN == 0 && k % BK == 0 && ((m + BM - 1) / BM) * (n / BN) <= h->num_cu / 2 &&
                          ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && lda % 2 == 0 &&
                          ldb % 2 == 0 && ldc % 2 == 0;
@@ -347,7 +400,18 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
             LSX_HIP(hipGetLastError());
             return LSX_OK;
         }
-        go(true, fm, fn, 0, 0);                 // interior
+        if (h->gemm_queue && fm > 0 && fn > 0 && h->gemm_counters) {
+            h->gemm_queue_used = 1;
+            // interior tiles through the work queue (look-ahead driver; counters zeroed by the driver)
+            const dim3 grid(2 * h->num_cu);
+            int *ctr = h->gemm_counters + 8 * (h->gemm_counter_set++ % h->gemm_counter_sets);
+            if (waves == 8)
+                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 4>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word);
+            else
+                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 2>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word);
+        } else {
+            go(true, fm, fn, 0, 0);                 // interior
+        }
         go(false, tm - fm, tn, fm, 0);          // bottom strip (all columns)
         go(false, fm, tn - fn, 0, fn);          // right strip (complete tile rows only)
     }

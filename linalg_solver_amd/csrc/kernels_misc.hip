@@ -208,6 +208,62 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
     return LSX_OK;
 }
 
+// Every panel's interchanges on the columns LEFT of it, for the whole factorisation in one launch (look-ahead
+// driver with the XCD-scope panel: nothing may be launched beside a running panel, see api.hip, so the
+// left-hand interchanges no longer trail each step).  Columns are independent: a workgroup owns a 32-column chunk
+// and applies the gather lists of all panels right of it in factorisation order.  lists[s] (256 int2) belongs to
+// the panel that starts at row/column k0 + s * nb.
+template <typename T, int CW, int VW>
+__global__ __launch_bounds__(256) void laswp_left_all_kernel(T *__restrict__ A, int lda, int k0, int nb, int nsteps,
+                                                             const int2 *__restrict__ lists) {
+    const int c_end = (blockIdx.x + 1) * CW * VW;   // first column right of this chunk
+    for (int s = 0; s < nsteps; ++s) {
+        const int ks = k0 + s * nb;
+        if (ks < c_end) continue;                    // the chunk is not entirely left of panel s (uniform)
+        laswp_moves_body<T, CW, VW>(blockIdx.x, ks / VW, A, lda, ks, lists + 256 * s, 0x7fffffff, 0);
+        __syncthreads();                             // the body's index arrays are rewritten next trip
+    }
+}
+
+// columns [0, k_last) where k_last = k0 + (nsteps - 1) * nb is the last panel's first column
+template <typename T>
+int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nsteps, const void *lists) {
+    const int k_last = k0 + (nsteps - 1) * nb;
+    if (nsteps <= 0 || k_last <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_LASWP, 0, 2.0 * sizeof(T) * 128 * (double)k_last * nsteps);
+    constexpr int VW = 16 / (int)sizeof(T);
+    if (((size_t)A % 16 == 0) && lda % VW == 0 && k0 % 32 == 0 && nb % 32 == 0) {
+        constexpr int CW = 32 / VW;
+        hipLaunchKernelGGL((laswp_left_all_kernel<T, CW, VW>), dim3((k_last + 31) / 32), dim3(256), 0, h->stream, A,
+                           lda / VW, k0, nb, nsteps, (const int2 *)lists);
+    } else {
+        if (k0 % 32 || nb % 32) { set_error("laswp_left_all: panel starts must be multiples of 32"); return LSX_ERR_INTERNAL; }
+        hipLaunchKernelGGL((laswp_left_all_kernel<T, 32, 1>), dim3((k_last + 31) / 32), dim3(256), 0, h->stream, A, lda,
+                           k0, nb, nsteps, (const int2 *)lists);
+    }
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// One small workgroup that waits (bounded) until *word >= target: the look-ahead driver puts it in front of the
+// XCD-scope panel so that the trailing update launched beside it has had its workgroups dealt to the panel's XCD
+// (where they leave at once) BEFORE the panel's workgroups fill that XCD's CUs -- a kernel launched once they
+// are resident could not finish before the panel does, because an eighth of its workgroups is dealt to that XCD.
+__global__ __launch_bounds__(64) void gate_kernel(const int *word, int target, int limit) {
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < limit; ++i) {
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+int launch_gate(lsx_handle_t h, const int *word, int target) {
+    // ~0.25 us per poll: give up after ~0.5 ms (the update was not launched at all, or is far behind)
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, h->stream, word, target, 2000);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
 // the same for a plain column range
 template <typename T>
 int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
@@ -945,6 +1001,7 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     template int launch_fill<T>(lsx_handle_t, int, uint64_t, int, int, T *, int, int, int);       \
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \
     template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
+    template int launch_laswp_left_all<T>(lsx_handle_t, T *, int, int, int, int, const void *);   \
     template int launch_laswp_moves_around<T>(lsx_handle_t, int, T *, int, int, int, int);        \
     template int launch_chain_head<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int);  \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \

@@ -38,67 +38,21 @@
 
 namespace lsx {
 
-__device__ __forceinline__ double readlane_t(double v, int l) { return readlane_d(v, l); }
-__device__ __forceinline__ float readlane_t(float v, int l) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
-}
-
 constexpr int XLOAD = 16;  // sc1: device scope
 constexpr int PP_STAGGER = 4;  // s_sleep units (64 clk) between the two shots at a block start
 
-// ---- reductions with the DPP move fused into the VALU op (v_max_u32_dpp / v_min_i32_dpp): one
-// instruction per step.  An arg-max over fp64 magnitudes is three such phases on the bit pattern
-// (non-negative doubles order like unsigned 64-bit integers): high word, low word, then the lowest
-// row index among the lanes that hold the maximum.
-__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
-    v = max(v, (unsigned)dpp_i<0xB1>((int)v));
-    v = max(v, (unsigned)dpp_i<0x4E>((int)v));
-    v = max(v, (unsigned)dpp_i<0x141>((int)v));
-    v = max(v, (unsigned)dpp_i<0x140>((int)v));
-    return v;
-}
-__device__ __forceinline__ int row16_min_i32(int v) {
-    v = min(v, dpp_i<0xB1>(v));
-    v = min(v, dpp_i<0x4E>(v));
-    v = min(v, dpp_i<0x141>(v));
-    v = min(v, dpp_i<0x140>(v));
-    return v;
-}
-// combine the 16-lane rows starting at lane0 (NROW of them) through scalar registers
-template <int NROW>
-__device__ __forceinline__ unsigned rows_max_u32(unsigned v, int lane0) {
-    unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, lane0);
-#pragma unroll
-    for (int k = 1; k < NROW; ++k) r = max(r, (unsigned)__builtin_amdgcn_readlane((int)v, lane0 + 16 * k));
-    return r;
-}
-template <int NROW>
-__device__ __forceinline__ int rows_min_i32(int v, int lane0) {
-    int r = __builtin_amdgcn_readlane(v, lane0);
-#pragma unroll
-    for (int k = 1; k < NROW; ++k) r = min(r, __builtin_amdgcn_readlane(v, lane0 + 16 * k));
-    return r;
-}
-// arg-max over NROW 16-lane rows starting at lane0: key = (khi, klo) bit pattern of |a| (0 for "no
-// candidate"), idx = row (INT_MAX for none).  Returns the winning row, wave-uniform; INT_MAX: none.
-// All 64 lanes must be active.
-template <int NROW>
-__device__ __forceinline__ int argmax_rows(unsigned khi, unsigned klo, int idx, int lane0) {
-    const unsigned mhi = rows_max_u32<NROW>(row16_max_u32(khi), lane0);
-    const bool top = khi == mhi;
-    const unsigned mlo = rows_max_u32<NROW>(row16_max_u32(top ? klo : 0u), lane0);
-    return rows_min_i32<NROW>(row16_min_i32((top & (klo == mlo)) ? idx : 0x7fffffff), lane0);
-}
-
 // KS = header slots per polling lane (G <= 64 * KS)
-template <typename T, int RT, int NT, int KS, bool DBG>
-__global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb, T *__restrict__ P, int ldp,
-                                                                  int row0, int col0,
-                                                                  int32_t *__restrict__ ipiv,
-                                                                  int *__restrict__ info, char *hdr,
-                                                                  XGran *xrow, int *status,
-                                                                  unsigned long long *dbg,
-                                                                  int2 *__restrict__ moves) {
+// XCD = true: the exchange runs at XCD scope.  Only the workgroups with blockIdx.x % 8 == 0 take part (round-robin
+// dispatch puts them on one XCD); their header / granule stores are PLAIN stores, which stay in that XCD's L2,
+// and the polling loads bypass L1 only (`sc1`), so one hop costs an L2 round trip instead of a trip through
+// the fabric.  Placement is verified, never assumed: every participant publishes its XCC id device-scope
+// before column 0 and a panel whose participants do not share one id runs the device-scope protocol instead.
+template <typename T, int RT, int NT, int KS, bool DBG, bool XCD>
+__device__ __forceinline__ void panel_pipe_body(const int G, const int g, int m, int jb, T *__restrict__ P, int ldp,
+                                                int row0, int col0, int32_t *__restrict__ ipiv,
+                                                int *__restrict__ info, char *hdr, XGran *xrow, int *status,
+                                                unsigned long long *dbg, int2 *__restrict__ moves) {
+    constexpr int XSTORE = XCD ? 0 : 16;   // cache policy of the exchange stores: plain (L2) or sc1 (write-through)
     constexpr int NTY = NT / 16;   // thread rows; the owners of one column are NTY consecutive lanes
     constexpr int RB = NTY * RT;   // panel rows per workgroup
     constexpr int NONE = 0x7fffffff;
@@ -114,7 +68,6 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
     __builtin_amdgcn_s_setprio(3);
     // an earlier panel of this factorisation already failed (exchange time-out): do not spin again
     if (info && *info < 0) return;
-    const int G = gridDim.x, g = blockIdx.x;
     const int tid = threadIdx.x, ty = tid % NTY, tx = tid / NTY;
     const int lane = tid & 63, wave = tid >> 6;
     const int base = g * RB;
@@ -241,7 +194,7 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
         const unsigned long long vb = (unsigned long long)__double_as_longlong(val);
         u4 h;
         h.x = (unsigned)vb; h.y = (unsigned)(vb >> 32); h.z = (unsigned)row; h.w = (unsigned)(jn + 1);
-        __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, ((jn & 1) * G + g) * HDR_STRIDE, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(h, r_hdr, ((jn & 1) * G + g) * HDR_STRIDE, 0, XSTORE);
     };
     // the thread row holding slice-local row cl publishes it as granules of column jn.  ALWAYS
     // exactly 8 store instructions per wave (every wave holds every thread row): without a candidate
@@ -269,8 +222,12 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
                         const int offc = off + 16 * c;
                         // s_nop: a store wider than 64 bits reads its data registers for two more
                         // cycles (hipcc pads its own stores; it does not look inside asm)
-                        asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1"
-                                     : : "v"(v), "v"(offc), "s"(d_row));
+                        if (XCD)
+                            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1"
+                                         : : "v"(v), "v"(offc), "s"(d_row));
+                        else
+                            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1"
+                                         : : "v"(v), "v"(offc), "s"(d_row));
                     }
                 }
         }
@@ -551,10 +508,63 @@ __global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb,
     }
 }
 
-template <typename T, int RT, int NT, int KS>
+template <typename T, int RT, int NT, int KS, bool DBG>
+__global__ __launch_bounds__(NT, NT / 256) void panel_pipe_kernel(int m, int jb, T *__restrict__ P, int ldp,
+                                                                  int row0, int col0,
+                                                                  int32_t *__restrict__ ipiv,
+                                                                  int *__restrict__ info, char *hdr,
+                                                                  XGran *xrow, int *status,
+                                                                  unsigned long long *dbg,
+                                                                  int2 *__restrict__ moves) {
+    panel_pipe_body<T, RT, NT, KS, DBG, false>(gridDim.x, blockIdx.x, m, jb, P, ldp, row0, col0, ipiv, info, hdr, xrow,
+                                               status, dbg, moves);
+}
+
+// The XCD-scope launch: 8 * G workgroups, the G with blockIdx.x % 8 == 0 take part.  `xcc` (G words, zero at
+// launch) is the placement handshake: participant g stores 1 + its XCC id write-through, everybody reads all G
+// (bounded spin) and takes the XCD-scope protocol only if all ids agree -- the decision is a function of the
+// same G words for every participant, so they all take the same branch.
+template <typename T, int RT, int NT, int KS, bool DBG>
+__global__ __launch_bounds__(NT, NT / 256) void panel_pipe_xcd_kernel(int m, int jb, T *__restrict__ P, int ldp,
+                                                                      int row0, int col0,
+                                                                      int32_t *__restrict__ ipiv,
+                                                                      int *__restrict__ info, char *hdr,
+                                                                      XGran *xrow, int *status,
+                                                                      unsigned long long *dbg,
+                                                                      int2 *__restrict__ moves, int *xcc) {
+    if (blockIdx.x & 7) return;
+    const int G = gridDim.x >> 3, g = blockIdx.x >> 3;
+    __shared__ int s_same;
+    if (threadIdx.x < 64) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(id));
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&xcc[g], (int)id + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool pend = lane < G, same = true;
+        int spins = 0;
+        while (__any(pend)) {
+            const int v = __hip_atomic_load(&xcc[lane < G ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pend && v != 0) { pend = false; same = v == (int)id + 1; }
+            if (++spins > SPIN_LIMIT) { same = false; break; }
+        }
+        const bool all_same = !__any(!same);
+        if (lane == 0) {
+            s_same = all_same ? 1 : 0;
+            if (DBG && dbg) dbg[g * 8 + 7] = ((unsigned long long)id << 8) | (all_same ? 1u : 0u);
+        }
+    }
+    __syncthreads();
+    if (s_same)
+        panel_pipe_body<T, RT, NT, KS, DBG, true>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, hdr, xrow, status, dbg, moves);
+    else
+        panel_pipe_body<T, RT, NT, KS, DBG, false>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, hdr, xrow, status, dbg, moves);
+}
+
+template <typename T, int RT, int NT, int KS, bool XCDL>
 static int panel_pipe_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp, int row0, int col0,
                              int32_t *d_ipiv, int *d_info) {
-    // exchange area in scratch: status | headers[2][G] (HDR_STRIDE apart) | granule rows[2][G][128]
+    // exchange area in scratch: status (+ the XCC handshake words at +64) | headers[2][G] (HDR_STRIDE apart) |
+    // granule rows[2][G][128]
     const size_t hdr_bytes = (size_t)2 * G * HDR_STRIDE;
     const size_t need = 256 + hdr_bytes + (size_t)2 * G * PC_COLS * sizeof(XGran);
     const size_t dbg_off = (need + 255) & ~(size_t)255;
@@ -567,19 +577,28 @@ static int panel_pipe_launch(lsx_handle_t h, int G, int m, int jb, T *P, int ldp
     }
     char *base = (char *)h->scratch + base_off;
     int *status = (int *)base;
+    int *xcc = (int *)(base + 64);
     char *hdr = base + 256;
     XGran *xrow = (XGran *)(base + 256 + hdr_bytes);
     // status word, headers AND granules are zero at EVERY launch (epoch 0 never matches): cleared here, or
     // by the look-ahead driver beside the previous panel so that the memset is not on the panel-to-panel chain
     if (!driver_clears) LSX_HIP(hipMemsetAsync(base, 0, h->panel_debug ? total : need, h->stream));
-    if (h->panel_debug) {
-        unsigned long long *dbg = (unsigned long long *)(base + dbg_off);
+    unsigned long long *dbg = h->panel_debug ? (unsigned long long *)(base + dbg_off) : nullptr;
+    if constexpr (XCDL) {
+        if (h->panel_debug)
+            hipLaunchKernelGGL((panel_pipe_xcd_kernel<T, RT, NT, KS, true>), dim3(8 * G), dim3(NT), 0, h->stream, m, jb, P,
+                               ldp, row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves, xcc);
+        else
+            hipLaunchKernelGGL((panel_pipe_xcd_kernel<T, RT, NT, KS, false>), dim3(8 * G), dim3(NT), 0, h->stream, m, jb, P,
+                               ldp, row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves, xcc);
+    } else {
+      if (h->panel_debug) {
         hipLaunchKernelGGL((panel_pipe_kernel<T, RT, NT, KS, true>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
                            row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves);
-    } else {
+      } else {
         hipLaunchKernelGGL((panel_pipe_kernel<T, RT, NT, KS, false>), dim3(G), dim3(NT), 0, h->stream, m, jb, P, ldp,
-                           row0, col0, d_ipiv, d_info, hdr, xrow, status, (unsigned long long *)nullptr,
-                           (int2 *)h->moves);
+                           row0, col0, d_ipiv, d_info, hdr, xrow, status, dbg, (int2 *)h->moves);
+      }
     }
     LSX_HIP(hipGetLastError());
     h->moves_valid = true;
@@ -597,6 +616,19 @@ int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int 
     int nt = h->panel_nt, rt = h->panel_rt;
     auto rows = [](int nt_, int rt_) { return nt_ / 16 * rt_; };
     auto wgs = [&](int nt_, int rt_) { return (m + rows(nt_, rt_) - 1) / rows(nt_, rt_); };
+    // XCD-scope exchange (option panel_xcd): at most 32 workgroups, one per CU of one XCD -- 256-row slices
+    // (512 threads x 8 rows) above 4096 rows, 128-row slices (512 x 4) down to 2048, 64-row slices below
+    if (h->panel_xcd && m <= 32 * 256) {
+        int xnt = 512, xrt = 8;
+        if (m <= 32 * 64) { xnt = 256; xrt = 4; }
+        else if (m <= 32 * 128) { xnt = 512; xrt = 4; }
+        const int G = wgs(xnt, xrt);
+#define LSX_PPX(RT_, NT_)                          \
+        if (xrt == RT_ && xnt == NT_)              \
+            return panel_pipe_launch<T, RT_, NT_, 1, true>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+        LSX_PPX(8, 512) LSX_PPX(4, 512) LSX_PPX(4, 256)
+#undef LSX_PPX
+    }
     if (h->panel_nt == 0) {  // measured: one header per polling lane (<= 64 workgroups) wins
         nt = 256, rt = 4;
         if (wgs(nt, rt) > 64) nt = 512;
@@ -608,7 +640,7 @@ int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int 
     const int ks = G <= 64 ? 1 : (G <= 128 ? 2 : 4);
 #define LSX_PP(RT_, NT_, KS_)                     \
     if (rt == RT_ && nt == NT_ && ks == KS_)      \
-        return panel_pipe_launch<T, RT_, NT_, KS_>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+        return panel_pipe_launch<T, RT_, NT_, KS_, false>(h, G, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
     LSX_PP(4, 256, 1) LSX_PP(4, 256, 2) LSX_PP(4, 256, 4)
     LSX_PP(4, 512, 1) LSX_PP(4, 512, 2) LSX_PP(4, 512, 4)
     LSX_PP(8, 512, 1) LSX_PP(8, 512, 2) LSX_PP(8, 512, 4)
@@ -617,7 +649,7 @@ int panel_pipelined(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int 
 }
 
 size_t panel_pipe_area_bytes(lsx_handle_t h, int m) {
-    if (h->panel_mode != 3 || h->panel_debug || h->nb > PC_COLS) return 0;
+    if (h->panel_mode < 3 || h->panel_debug || h->nb > PC_COLS) return 0;
     if (h->panel_nt != 0 && h->panel_nt != 256 && h->panel_nt != 512) return 0;
     if (!(h->panel_rt == 4 || (h->panel_rt == 8 && h->panel_nt == 512))) return 0;
     if (m > 256 * (h->num_cu < 256 ? h->num_cu : 256)) return 0;

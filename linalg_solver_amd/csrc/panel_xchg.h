@@ -61,5 +61,54 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
                             __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+__device__ __forceinline__ double readlane_t(double v, int l) { return readlane_d(v, l); }
+__device__ __forceinline__ float readlane_t(float v, int l) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
+}
+
+// ---- reductions with the DPP move fused into the VALU op (v_max_u32_dpp / v_min_i32_dpp): one
+// instruction per step.  An arg-max over fp64 magnitudes is three such phases on the bit pattern
+// (non-negative doubles order like unsigned 64-bit integers): high word, low word, then the lowest
+// row index among the lanes that hold the maximum.
+__device__ __forceinline__ unsigned row16_max_u32(unsigned v) {
+    v = max(v, (unsigned)dpp_i<0xB1>((int)v));
+    v = max(v, (unsigned)dpp_i<0x4E>((int)v));
+    v = max(v, (unsigned)dpp_i<0x141>((int)v));
+    v = max(v, (unsigned)dpp_i<0x140>((int)v));
+    return v;
+}
+__device__ __forceinline__ int row16_min_i32(int v) {
+    v = min(v, dpp_i<0xB1>(v));
+    v = min(v, dpp_i<0x4E>(v));
+    v = min(v, dpp_i<0x141>(v));
+    v = min(v, dpp_i<0x140>(v));
+    return v;
+}
+// combine the 16-lane rows starting at lane0 (NROW of them) through scalar registers
+template <int NROW>
+__device__ __forceinline__ unsigned rows_max_u32(unsigned v, int lane0) {
+    unsigned r = (unsigned)__builtin_amdgcn_readlane((int)v, lane0);
+#pragma unroll
+    for (int k = 1; k < NROW; ++k) r = max(r, (unsigned)__builtin_amdgcn_readlane((int)v, lane0 + 16 * k));
+    return r;
+}
+template <int NROW>
+__device__ __forceinline__ int rows_min_i32(int v, int lane0) {
+    int r = __builtin_amdgcn_readlane(v, lane0);
+#pragma unroll
+    for (int k = 1; k < NROW; ++k) r = min(r, __builtin_amdgcn_readlane(v, lane0 + 16 * k));
+    return r;
+}
+// arg-max over NROW 16-lane rows starting at lane0: key = (khi, klo) bit pattern of |a| (0 for "no
+// candidate"), idx = row (INT_MAX for none).  Returns the winning row, wave-uniform; INT_MAX: none.
+// All 64 lanes must be active.
+template <int NROW>
+__device__ __forceinline__ int argmax_rows(unsigned khi, unsigned klo, int idx, int lane0) {
+    const unsigned mhi = rows_max_u32<NROW>(row16_max_u32(khi), lane0);
+    const bool top = khi == mhi;
+    const unsigned mlo = rows_max_u32<NROW>(row16_max_u32(top ? klo : 0u), lane0);
+    return rows_min_i32<NROW>(row16_min_i32((top & (klo == mlo)) ? idx : 0x7fffffff), lane0);
+}
+
 
 }  // namespace lsx

@@ -36,6 +36,9 @@ def dev():
     return DeviceSolver()
 
 
+DEFAULT_PANEL = 4   # common.h: panel_mode (XCD-scope exchange; taller panels than one XCD holds take mode 3)
+
+
 def test_native_library_is_the_compute_path(la):
     import ctypes
 
@@ -137,7 +140,7 @@ def test_getrf_matches_cpu_twin(la, n):
     try:
         LU, ipiv, info = dense.lu_factor(A)
     finally:
-        h.set_option("panel", 3)
+        h.set_option("panel", DEFAULT_PANEL)
     oLU, oipiv, oinfo = capi.getrf(A)
     assert info == oinfo == 0
     assert np.array_equal(ipiv, oipiv), "pivot sequence differs from the partial-pivot twin"
@@ -166,7 +169,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
             h.set_option("kblock", kb)
             results.append(dense.lu_factor(A))
     finally:
-        h.set_option("panel", 3)
+        h.set_option("panel", DEFAULT_PANEL)
         h.set_option("panel_rt", 4)
         h.set_option("panel_nt", 0)
         h.set_option("lookahead", 1)
@@ -177,7 +180,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
         h.set_option("panel", 2)
         LUb, ipivb, infob = dense.lu_factor(A)
     finally:
-        h.set_option("panel", 3)
+        h.set_option("panel", DEFAULT_PANEL)
     assert infob == 0 and np.array_equal(ipivb, results[3][1]) and np.array_equal(LUb, results[3][0])
     # ... and so does the pipelined panel (mode 3, the default) in every workgroup shape
     try:
@@ -189,10 +192,22 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
             LUp, ipivp, infop = dense.lu_factor(A)
             assert infop == 0 and np.array_equal(ipivp, results[3][1]) and np.array_equal(LUp, results[3][0]), \
                 f"pipelined panel nt={nt} rt={rt} lookahead={look} differs"
+        # ... and the XCD-scope panel (mode 4, the default), alone and under its own look-ahead schedule
+        h.set_option("panel_nt", 0)
+        h.set_option("panel_rt", 4)
+        h.set_option("lookahead_min", 128)
+        for look in (0, 1):
+            h.set_option("panel", 4)
+            h.set_option("lookahead", look)
+            LUx, ipivx, infox = dense.lu_factor(A)
+            assert infox == 0 and np.array_equal(ipivx, results[3][1]) and np.array_equal(LUx, results[3][0]), \
+                f"XCD-scope panel lookahead={look} differs"
     finally:
+        h.set_option("panel", DEFAULT_PANEL)
         h.set_option("panel_nt", 0)
         h.set_option("panel_rt", 4)
         h.set_option("lookahead", 1)
+        h.set_option("lookahead_min", 0)
     # tile height and look-ahead do not change a single bit
     assert np.array_equal(results[1][1], results[0][1]) and np.array_equal(results[1][0], results[0][0])
     assert np.array_equal(results[2][1], results[3][1]) and np.array_equal(results[2][0], results[3][0])
@@ -206,7 +221,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
     assert relerr(LU, oLU) < TOL64
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
 @pytest.mark.parametrize("n", [16, 200, 513])
 def test_getrf_cooperative_panel_integer_and_singular(la, n, mode):
     from linalg_solver_amd import dense, gen
@@ -221,7 +236,7 @@ def test_getrf_cooperative_panel_integer_and_singular(la, n, mode):
         _, _, sinfo = dense.lu_factor(S)
         LU32, ipiv32, info32 = dense.lu_factor(A.astype(np.float32), dtype=np.float32)
     finally:
-        h.set_option("panel", 3)
+        h.set_option("panel", DEFAULT_PANEL)
     assert info == 0 and _plu_residual(A, LU, ipiv) < 50 * n * 2.3e-16
     assert np.max(np.abs(np.tril(LU, -1))) <= 1.0
     assert sinfo == capi.getrf(S)[2] == 6
@@ -577,7 +592,8 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
     outs = []
     try:
         dev.h.set_option("lookahead_min", 128)
-        for look in (0, 1, 2, 3):
+        for mode, look in ((3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1)):
+            dev.h.set_option("panel", mode)
             dev.h.set_option("lookahead", look)
             LU = A0.clone()
             ipiv, info = dev.getrf_(LU)
@@ -585,13 +601,15 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
             assert int(info.item()) == 0
             outs.append((LU, ipiv.clone()))
     finally:
+        dev.h.set_option("panel", DEFAULT_PANEL)
         dev.h.set_option("lookahead", 1)
         dev.h.set_option("lookahead_min", 0)
     for LU, ipiv in outs[1:]:
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
-@pytest.mark.parametrize("n,dtype", [(7168, "f64"), (7203, "f64"), (9000, "f64"), (10240, "f32"), (10307, "f32")])
+@pytest.mark.parametrize("n,dtype", [(3072, "f64"), (3101, "f64"), (7168, "f64"), (7203, "f64"), (8192, "f64"), (9000, "f64"),
+                                     (4096, "f32"), (4131, "f32"), (10240, "f32"), (10307, "f32")])
 def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
     """At and just above the orders where the look-ahead driver takes over by default (aligned and odd): same
     bits as the sequential driver, and P A = L U to working precision."""
@@ -640,7 +658,8 @@ def test_lookahead_variants_are_bit_identical_at_8192(dev):
     dev.fill_(A0, gen.U11, 4)
     outs = []
     try:
-        for look in (0, 1, 2):
+        for mode, look in ((3, 0), (3, 1), (3, 2), (4, 0), (4, 1)):
+            dev.h.set_option("panel", mode)
             dev.h.set_option("lookahead", look)
             LU = A0.clone()
             ipiv, info = dev.getrf_(LU)
@@ -648,6 +667,7 @@ def test_lookahead_variants_are_bit_identical_at_8192(dev):
             assert int(info.item()) == 0
             outs.append((LU, ipiv.clone()))
     finally:
+        dev.h.set_option("panel", DEFAULT_PANEL)
         dev.h.set_option("lookahead", 1)
     for LU, ipiv in outs[1:]:
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])

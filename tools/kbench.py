@@ -144,6 +144,140 @@ def main():
         dev.h.set_option("panel_debug", 0)
         dev.h.set_option("panel_nt", 0)
         dev.h.set_option("panel", 3)
+    if "xchg" in args.what:
+        # floor of the panel's per-column exchange: one all-gather round by store policy and placement
+        for mode, nm in ((2, "ping-pong (one-way = half)"), (0, "header all-gather"), (1, "header all-gather + winner row")):
+            for G, stride, wt in ((32, 8, False), (32, 8, True), (32, 1, True), (64, 1, True), (32, 1, False)):
+                if mode == 2 and G == 64:
+                    continue
+                us, ids, nf = dev.h.xchg_probe(mode, G, stride, wt, 4000)
+                print(f"xchg {nm}: G={G} stride={stride} stores={'sc1' if wt else 'plain'}: {us:.3f} us/round  "
+                      f"failures={nf}  xcc ids={sorted(set(ids))} (participant 0 on {ids[0]}, 1 on {ids[1]})", flush=True)
+    if "panelx" in args.what:
+        import numpy as np
+        # device-scope pipelined panel (panel=3) / the same with XCD-scope stores (panel_xcd=1) / XCD kernel (panel=4)
+        variants = (("p3", 3, 0), ("p3x", 3, 1), ("p4", 4, 0))
+        dev.h.set_option("panel_nt", 0)
+        dev.h.set_option("panel_rt", 4)
+        dt = torch.float32 if args.f32 else torch.float64
+        for m in (8192, 6000, 4096, 3000, 2048, 1024, 384, 257, 100):
+            for nbw in (args.nb, 100, 17):
+                for kind in (gen.U11, gen.INT5):
+                    P0 = torch.empty(m, nbw, dtype=dt, device="cuda")
+                    dev.fill_(P0, kind, 3)
+                    outs = []
+                    for nm, mode, xcd in variants:
+                        dev.h.set_option("panel", mode)
+                        dev.h.set_option("panel_xcd", xcd)
+                        P = P0.clone()
+                        ipiv = torch.zeros(nbw, dtype=torch.int32, device="cuda")
+                        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                        dev.panel_(P, 0, ipiv, info)
+                        torch.cuda.synchronize()
+                        outs.append((P, ipiv.clone(), int(info.item())))
+                    res = []
+                    for k in (1, 2):
+                        same = torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]) and outs[0][2] == outs[k][2]
+                        res.append(f"{variants[k][0]}={'same' if same else 'MISMATCH'}(info {outs[k][2]})")
+                    print(f"panelx check m={m} jb={nbw} kind={kind}: " + " ".join(res), flush=True)
+        for nm, mode, xcd in variants:
+            dev.h.set_option("panel", mode)
+            dev.h.set_option("panel_xcd", xcd)
+            for m in (8192, 6144, 4096, 2048, 1024, 256):
+                P0 = torch.empty(m, args.nb, dtype=dt, device="cuda")
+                dev.fill_(P0, gen.U11, 3)
+                ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                P = P0.clone()
+
+                def run():
+                    P.copy_(P0)
+                    dev.panel_(P, 0, ipiv, info)
+                tmin, tmed = timeit(run, reps=7, warm=2)
+                tcopy, _ = timeit(lambda: P.copy_(P0), reps=7, warm=2)
+                t = tmin - tcopy
+                print(f"panel {nm} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)", flush=True)
+        names = ["own: headers+winner", "own: multipliers+granules", "own: update+choose+announce", "own: barrier",
+                 "next wave: barrier wait", "next wave: far granules+update", "next wave: publish", "own: second block behind the barrier"]
+        dev.h.set_option("panel", 4)
+        dev.h.set_option("panel_xcd", 0)
+        dev.h.set_option("panel_debug", 1)
+        rows = 256 if not args.f32 else 512
+        for m in (8192, 4096, 2048, 256):
+            P = torch.empty(m, args.nb, dtype=dt, device="cuda")
+            ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            for rep in range(2):
+                dev.fill_(P, gen.U11, 3)
+                dev.panel_(P, 0, ipiv, info)
+            torch.cuda.synchronize()
+            G = (m + rows - 1) // rows
+            need = 256 + 2 * G * 128 + 4 * G * 128 * 16
+            off = (need + 255) & ~255
+            raw = np.frombuffer(dev.h.read_scratch(off, G * 128), dtype=np.uint64).reshape(G, 16)
+            us = raw.astype(np.float64) / 100.0 / args.nb
+            tag = f" xcc ids {sorted(set((raw[:, 15] >> 8).tolist()))} same-flag {sorted(set((raw[:, 15] & 1).tolist()))}"
+            print(f"stamps4 m={m} G={G}: us per column (mean | max over workgroups)   owner total {us[:, [0, 1, 2, 3, 7]].sum(1).mean():.2f}{tag}")
+            for i, nm in enumerate(names[:8]):
+                print(f"   {nm:30s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
+        dev.h.set_option("panel_debug", 0)
+        dev.h.set_option("panel", 3)
+    if "cumask" in args.what:
+        from collections import Counter
+        pats = {
+            "no mask": None,
+            "bits 0..223": range(0, 224),
+            "bits 32..255": range(32, 256),
+            "bits i%8!=0": [i for i in range(256) if i % 8 != 0],
+            "bits i%8==0": [i for i in range(256) if i % 8 == 0],
+            "bits 0..31": range(0, 32),
+            "bits i%8==3": [i for i in range(256) if i % 8 == 3],
+            "bits 0..127": range(0, 128),
+            "bits i%2==0": range(0, 256, 2),
+        }
+        for nm, bits in pats.items():
+            try:
+                res = dev.h.cu_mask_probe(bits, 2048)
+            except Exception as e:  # noqa: BLE001
+                print(f"cumask {nm}: FAILED {e}")
+                continue
+            xc = Counter(x for x, _ in res)
+            cus = Counter((x, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15) for x, hw in res)
+            first8 = [x for x, _ in res[:16]]
+            print(f"cumask {nm}: blocks per xcc {dict(sorted(xc.items()))}  distinct (xcc,se,sh,cu) {len(cus)}  first blocks' xcc {first8}", flush=True)
+    if "lu4" in args.what:
+        # whole factorisation: device-scope panel (3) against the XCD-scope panel (4), both drivers; same bits
+        dt = torch.float32 if args.f32 else torch.float64
+        for n in (args.n,) if args.n != 8192 else (8192, 4096, 12288):
+            A0 = torch.empty(n, n, dtype=dt, device="cuda")
+            dev.fill_(A0, gen.U11, 1)
+            A = A0.clone()
+            ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            ref = None
+            for mode, look in ((3, 0), (3, 1), (4, 0), (4, 1)):
+                dev.h.set_option("panel", mode)
+                dev.h.set_option("lookahead", look)
+                dev.h.set_option("lookahead_min", 1024 if look else 0)
+
+                def run():
+                    A.copy_(A0)
+                    dev.getrf_(A, ipiv, info)
+                tmin, _ = timeit(run, reps=5, warm=2)
+                tcopy, _ = timeit(lambda: A.copy_(A0), reps=3, warm=1)
+                t = tmin - tcopy
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = (A.clone(), ipiv.clone())
+                    same = "reference"
+                else:
+                    same = "bit-identical" if (torch.equal(ref[0], A) and torch.equal(ref[1], ipiv)) else "MISMATCH"
+                dev.h.prof_reset(); dev.h.prof_enable(True); run(); torch.cuda.synchronize()
+                dev.h.prof_enable(False)
+                pr = dev.h.prof_read()
+                print(f"getrf n={n} panel={mode} lookahead={look}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  info={int(info.item())} {same}  phases "
+                      + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items() if v['ms'] > 0), flush=True)
+        dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 1); dev.h.set_option("lookahead_min", 0)
     if "pmc" in args.what:
         # workload for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`: two kernels of known byte counts
         # (calibration) followed by the trailing-update kernel at LU-like shapes
