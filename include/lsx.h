@@ -225,6 +225,13 @@ int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_t
 /* Diagnostics: launch nblocks workgroups on a stream created with the given CU mask (nwords = 0: the handle's
  * stream) and report where each landed: out[2 b] = XCC id, out[2 b + 1] = HW_ID register.  Synchronous. */
 int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out);
+/* Diagnostics: the 64 x 64 block inverses of the unit-lower jb x jb triangle at dT, through the fused head of the
+ * look-ahead chain (fused = 1: inverses + the gather list d_moves applied to ncols columns at dA in ONE launch) or
+ * through their own launch (fused = 0).  Device pointers, asynchronous on the handle's stream. */
+int lsx_diag_chain_head_f32(lsx_handle_t h, int fused, int jb, const float *dT, int ldt, float *dTinv, int ncols,
+                            float *dA, int lda, int row0, const int32_t *d_moves);
+int lsx_diag_chain_head_f64(lsx_handle_t h, int fused, int jb, const double *dT, int ldt, double *dTinv, int ncols,
+                            double *dA, int lda, int row0, const int32_t *d_moves);
 /* Copy a piece of the handle's device scratch to the host (stamped diagnostic builds). */
 int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes);
 

@@ -70,6 +70,8 @@ _SIGS = {
     "lsx_diag_mfma_peak": [_vp, _i, _i, _i, _dp, _dp],
     "lsx_diag_read_scratch": [_vp, C.c_size_t, _vp, C.c_size_t],
     "lsx_diag_xchg_probe": [_vp, _i, _i, _i, _i, _i, _dp, _ip, _ip],
+    "lsx_diag_chain_head_f32": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
+    "lsx_diag_chain_head_f64": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "lsx_diag_cu_mask_probe": [_vp, C.POINTER(C.c_uint32), _i, _i, C.POINTER(C.c_uint32)],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],

@@ -182,6 +182,9 @@ template <typename T>
 int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nsteps, const void *lists);
 int launch_gate(lsx_handle_t h, const int *word, int target);
 template <typename T>
+int diag_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                    const void *moves);
+template <typename T>
 int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, int hole_at, int hole_w);
 // Tinv (ceil(jb/64) blocks of 64x64) <- inverses of the 64x64 diagonal blocks of the
 // unit-lower (lower=1) or non-unit upper (lower=0) triangle stored at T.

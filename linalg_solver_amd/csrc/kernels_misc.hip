@@ -275,6 +275,14 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {
 // non-unit upper (lower=0) triangle: 16 x 16 blocks by substitution, then two
 // levels of 2x2 block merges  X21 = -X22 * (T21 * X11)  on the MFMA pipe,
 // everything LDS-resident.  Rows/columns past jb are treated as identity.
+// The substitution below spells its multiply-adds as explicit fused operations.  Written as `s -= a * b` the
+// contraction is hipcc's choice per inlining context, and it chose differently for the fp32 body inside
+// chain_head_kernel (lower = 1 constant-propagated) than inside trtri64_kernel: both inverses were accurate to
+// ~2e-6 but not the same bits, which is what the look-ahead driver's bit-identity tests caught in round 1
+// (tools/chk_chain_head.py; test_chain_head_fused_equals_separate).
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 constexpr int TB = 64;        // diagonal block edge
 constexpr int TLD = TB + 2;   // padded LDS leading dimension
 
@@ -355,7 +363,7 @@ __device__ __forceinline__ void trtri64_body(int bx, int by, int lower, int jb, 
                 T s = (i == c) ? T(1) : T(0);
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    if (t < i) s -= X[(o + i) * TLD + o + t] * ((t >= c) ? x[t] : T(0));
+                    if (t < i) s = fma_t(-X[(o + i) * TLD + o + t], (t >= c) ? x[t] : T(0), s);
                 x[i] = (i >= c) ? s : T(0);  // unit diagonal
             }
         } else {
@@ -365,11 +373,12 @@ __device__ __forceinline__ void trtri64_body(int bx, int by, int lower, int jb, 
                 T s = (i == c) ? T(1) : T(0);
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    if (t > i) s -= X[(o + i) * TLD + o + t] * ((t <= c) ? x[t] : T(0));
+                    if (t > i) s = fma_t(-X[(o + i) * TLD + o + t], (t <= c) ? x[t] : T(0), s);
                 x[i] = (i <= c) ? s / X[(o + i) * TLD + o + i] : T(0);
             }
         }
-        // single wave, lockstep: every lane's LDS reads above are issued before these writes
+        // single wave: a lane's x[i] depends on every read of row i, so all lanes' reads of a row are issued before any
+        // lane's write to it (LDS serves a wave's operations in order)
 #pragma unroll
         for (int i = 0; i < 16; ++i) X[(o + i) * TLD + o + c] = x[i];
     }
@@ -431,12 +440,6 @@ __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const
 // Returns 1 when the shapes do not allow the 16-byte path (the caller then issues the two launches).
 template <typename T>
 int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
-    // fp64 only.  In fp32 the inverses come out wrong when trtri64_body runs inside this fused kernel (isolated
-    // with the ragged-size look-ahead test: interchanges through the fused kernel + inverses from their own
-    // launch are right, the reverse is wrong; neither 16-byte alignment of the LDS arrays nor the register
-    // footprint of the interchange half (8- instead of 16-byte lanes) was it).  Cause not yet found, so fp32
-    // keeps the two launches.
-    if (sizeof(T) != 8) return 1;
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int CW = 32 / VW;
     if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
@@ -447,6 +450,23 @@ int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
+
+// Diagnostics (tests/test_gpu_parity.py: the fused chain head against the separate launches): block inverses of
+// the unit-lower triangle at Tm through chain_head_kernel with an all-void gather list on `ncols` columns of A.
+template <typename T>
+int diag_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                    const void *moves) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int CW = 32 / VW;
+    if (jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return LSX_ERR_ARG;
+    const int ntri = (jb + TB - 1) / TB;
+    hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
+                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)moves);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+template int diag_chain_head<float>(lsx_handle_t, int, const float *, int, float *, int, float *, int, int, const void *);
+template int diag_chain_head<double>(lsx_handle_t, int, const double *, int, double *, int, double *, int, int, const void *);
 
 template <typename T>
 int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv) {

@@ -780,3 +780,51 @@ def test_interchange_list_to_permutation(la, n, pattern):
                 want[[i, p]] = want[[p, i]]
         got = dense.lu_solve(np.eye(n), ipiv.astype(np.int32), b)
         assert np.array_equal(got, want), f"nrhs={nrhs}"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("jb,ld,ncols", [(128, 300, 128), (128, 300, 44), (64, 128, 64), (100, 304, 32)])
+def test_chain_head_fused_equals_separate(la, dtype, jb, ld, ncols):
+    """The fused head of the look-ahead chain (block inverses + gather list in one launch) gives the SAME BITS as
+    the block-inverse launch on its own, in both precisions, and both are the inverse.  Round 1 found the fp32
+    instantiation differing: hipcc contracted the substitution's multiply-adds differently per inlining context;
+    they are explicit fused operations now (kernels_misc.hip: fma_t)."""
+    import torch
+
+    from linalg_solver_amd import _native
+
+    h = la.default_handle()
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    fn = getattr(h.lib, f"lsx_diag_chain_head_{dtype}")
+    torch.manual_seed(jb + ld)
+    Tm = torch.rand(jb + 200, ld, dtype=tdt, device="cuda") - 0.5
+    A0 = torch.rand(jb + 200, ld, dtype=tdt, device="cuda")
+    mv = torch.full((256, 2), -1, dtype=torch.int32, device="cuda")
+    perm = torch.randperm(jb)[:40].tolist()
+    for i in range(0, 40, 2):   # 20 row exchanges
+        mv[i, 0], mv[i, 1] = perm[i], perm[i + 1]
+        mv[i + 1, 0], mv[i + 1, 1] = perm[i + 1], perm[i]
+    nblk = (jb + 63) // 64
+    outs, As = [], []
+    for fused in (0, 1):
+        Ti = torch.zeros(nblk * 4096, dtype=tdt, device="cuda")
+        A = A0.clone()
+        _native.check(fn(h._h, fused, jb, Tm.data_ptr(), ld, Ti.data_ptr(), ncols, A.data_ptr(), ld, 0, mv.data_ptr()),
+                      "diag_chain_head")
+        h.synchronize()
+        torch.cuda.synchronize()
+        outs.append(Ti)
+        As.append(A)
+    assert torch.equal(outs[0], outs[1]), "fused and separate block inverses differ"
+    for b in range(nblk):
+        w = min(64, jb - 64 * b)
+        L = torch.tril(Tm[64 * b:64 * b + w, 64 * b:64 * b + w].double(), -1) + torch.eye(w, dtype=torch.float64, device="cuda")
+        got = outs[1][4096 * b:4096 * (b + 1)].view(64, 64)[:w, :w].double()
+        assert float((got - torch.linalg.inv(L)).abs().max()) < (1e-4 if dtype == "f32" else 1e-12)
+    # the gather list moved the rows of the first ncols columns and nothing else
+    exp = A0.clone()
+    src = A0.clone()
+    for d, s_ in mv.tolist():
+        if d >= 0:
+            exp[d, :ncols] = src[s_, :ncols]
+    assert torch.equal(As[1], exp) and torch.equal(As[0], A0)
