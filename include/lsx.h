@@ -118,6 +118,21 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
  * the largest magnitude (same pivot positions, better conditioning). */
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda,
                  double *R, int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule);
+/* The fp32 forms of the three callers above (BASELINE config 5 computes in fp32): same meaning, fp32 MFMA tile. */
+int lsx_getri_f32(lsx_handle_t h, int n, const float *A, int lda, float *Ainv, int ldi,
+                  int *info, double *pivot_ratio);
+int lsx_det_f32(lsx_handle_t h, int n, const float *A, int lda, double *sign, double *mant,
+                int64_t *exp2);
+int lsx_rref_f32(lsx_handle_t h, int m, int n, int bar_col, const float *A, int lda,
+                 float *R, int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule);
+/* Mixed-precision solve: P A = L U in fp32, then `sweeps` (0..16, 2-3 suffice) corrections with the residual
+ * b - A x accumulated in fp64 -- the forward error goes from cond(A) * eps32 to the fp32 rounding of the solution
+ * of the fp64 system (config 5's "tolerance 1e-4 vs the fp64 result" is about the solution, which an unrefined fp32
+ * solve of a random 8192 x 8192 system misses).  X (fp32, n x nrhs) and / or X64 (fp64) receive the solution;
+ * last_correction = max|d| / max|x| of the last sweep (a convergence check: it should be ~eps32 or smaller). */
+int lsx_gesv_f32_refined(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb,
+                         float *X, int ldx, double *X64, int ldx64, int sweeps, int *info,
+                         double *pivot_ratio, double *last_correction);
 /* Traced row reduction: Matrix.row_reduce in the reference's own operation order (exact-zero pivot
  * test with first-non-zero row swap, normalise, eliminate below, separate backward pass;
  * linalg.py:547-629) with one IEEE rounding per operation, so R, the pivots and the step log are
@@ -159,6 +174,15 @@ int lsx_getrs_f64_dev(lsx_handle_t h, int n, int nrhs, const double *dLU, int ld
 int lsx_getri_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
                       double *dInv, int ldi);
 /* d_out[0]=sign, d_out[1]=mant, d_out[2]=(double)exp2 */
+/* fp32 forms of the two above, and the device-pointer mixed-precision solve: dA / dB are read, dLU receives the fp32
+ * factors, dX64 (n x nrhs fp64) the solution, dX32 (may be NULL) its fp32 rounding, d_stats (4 doubles, may be
+ * NULL) = max|d|, max|x| of the last sweep, then of the initial solve. */
+int lsx_getri_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv,
+                      float *dInv, int ldi);
+int lsx_det_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv, double *d_out);
+int lsx_gesv_f32_refined_dev(lsx_handle_t h, int n, int nrhs, const float *dA, int lda, float *dLU, int ldl,
+                             int32_t *d_ipiv, int *d_info, const float *dB, int ldb, double *dX64, int ldx,
+                             float *dX32, int ldf, int sweeps, double *d_stats);
 int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
                     double *d_out);
 int lsx_getrf_f32_dev(lsx_handle_t h, int n, float *dA, int lda, int32_t *d_ipiv, int *d_info);

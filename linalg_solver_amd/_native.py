@@ -46,6 +46,13 @@ _SIGS = {
     "lsx_rref_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, _ip, C.POINTER(_i), C.c_double, _i],
     "lsx_rref_trace_f64": [_vp, _i, _i, _i, _dp, _i, _dp, _i, C.c_void_p, _ip, C.POINTER(_i), _ip, _i,
                            C.POINTER(_i), _dp, C.c_void_p, _i],
+    "lsx_getri_f32": [_vp, _i, _fp, _i, _fp, _i, C.POINTER(_i), _dp],
+    "lsx_det_f32": [_vp, _i, _fp, _i, _dp, _dp, C.POINTER(C.c_int64)],
+    "lsx_rref_f32": [_vp, _i, _i, _i, _fp, _i, _fp, _i, _ip, C.POINTER(_i), C.c_double, _i],
+    "lsx_gesv_f32_refined": [_vp, _i, _i, _fp, _i, _fp, _i, _fp, _i, _dp, _i, _i, C.POINTER(_i), _dp, _dp],
+    "lsx_getri_f32_dev": [_vp, _i, _vp, _i, _vp, _vp, _i],
+    "lsx_det_f32_dev": [_vp, _i, _vp, _i, _vp, _vp],
+    "lsx_gesv_f32_refined_dev": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "lsx_getrf_f32": [_vp, _i, _fp, _i, _ip, C.POINTER(_i)],
     "lsx_getrs_f32": [_vp, _i, _i, _fp, _i, _ip, _fp, _i],
     "lsx_gesv_f32": [_vp, _i, _i, _fp, _i, _fp, _i, C.POINTER(_i), _dp],

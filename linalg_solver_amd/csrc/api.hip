@@ -743,6 +743,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws) (void)hipFree(h->ws);
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
+    if (h->ws4) (void)hipFree(h->ws4);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->moves_buf[0]) (void)hipFree(h->moves_buf[0]);
     if (h->moves_all) (void)hipFree(h->moves_all);
@@ -864,25 +865,29 @@ int lsx_gesv_f32(lsx_handle_t h, int n, int nrhs, const float *A, int lda, float
     return gesv_host<float>(h, n, nrhs, A, lda, B, ldb, info, pivot_ratio);
 }
 
-int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv, int ldi, int *info,
-                  double *pivot_ratio) {
+}  // extern "C"
+
+namespace lsx {
+
+template <typename T>
+static int getri_host(lsx_handle_t h, int n, const T *A, int lda, T *Ainv, int ldi, int *info, double *pivot_ratio) {
     LSX_ARG(h && n >= 0 && lda >= n && ldi >= n);
     if (info) *info = 0;
     if (pivot_ratio) *pivot_ratio = 1.0;
     if (n == 0) return LSX_OK;
     LSX_ARG(A && Ainv);
     const int ld = ld_for(n);
-    LSX_TRY(ensure_ws(h, 2 * pad256(sizeof(double) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
+    LSX_TRY(ensure_ws(h, 2 * pad256(sizeof(T) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
     Carver c(h->ws);
-    double *dA = c.take<double>((size_t)n * ld);
-    double *dI = c.take<double>((size_t)n * ld);
+    T *dA = c.take<T>((size_t)n * ld);
+    T *dI = c.take<T>((size_t)n * ld);
     int32_t *dp = c.take<int32_t>(n);
     int *dinfo = c.take<int>(1);
     double *dprobe = c.take<double>(2);
-    LSX_TRY(h2d<double>(h, n, n, A, lda, dA, ld));
-    LSX_TRY(launch_amax<double>(h, n, n, dA, ld, dprobe));
-    LSX_TRY(getrf_dev<double>(h, n, dA, ld, dp, dinfo));
-    LSX_TRY(launch_diag_minabs<double>(h, n, dA, ld, dprobe));
+    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(launch_amax<T>(h, n, n, dA, ld, dprobe));
+    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
     int hinfo = 0;
     double probe[2] = {0, 0};
     LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -895,32 +900,160 @@ int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv,
         return LSX_ERR_INTERNAL;
     }
     if (hinfo != 0) return LSX_OK;  // exactly singular: caller reports NoSolution (linalg.py:737)
-    LSX_TRY(getri_dev<double>(h, n, dA, ld, dp, dI, ld));
-    LSX_TRY(d2h<double>(h, n, n, dI, ld, Ainv, ldi));
+    LSX_TRY(getri_dev<T>(h, n, dA, ld, dp, dI, ld));
+    LSX_TRY(d2h<T>(h, n, n, dI, ld, Ainv, ldi));
     LSX_HIP(hipStreamSynchronize(h->stream));
     return LSX_OK;
 }
 
-int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, double *mant,
-                int64_t *exp2) {
+template <typename T>
+static int det_host(lsx_handle_t h, int n, const T *A, int lda, double *sign, double *mant, int64_t *exp2) {
     LSX_ARG(h && n >= 0 && lda >= n && sign && mant && exp2);
     if (n == 0) { *sign = 1; *mant = 0.5; *exp2 = 1; return LSX_OK; }  // det([]) = 1 (linalg.py:197-199)
     LSX_ARG(A);
     const int ld = ld_for(n);
-    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
+    LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)n * ld) + pad256(sizeof(int32_t) * n) + 1024));
     Carver c(h->ws);
-    double *dA = c.take<double>((size_t)n * ld);
+    T *dA = c.take<T>((size_t)n * ld);
     int32_t *dp = c.take<int32_t>(n);
     int *dinfo = c.take<int>(1);
     double *dout = c.take<double>(3);
-    LSX_TRY(h2d<double>(h, n, n, A, lda, dA, ld));
-    LSX_TRY(getrf_dev<double>(h, n, dA, ld, dp, dinfo));
-    LSX_TRY(launch_det<double>(h, n, dA, ld, dp, dout));
+    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    LSX_TRY(launch_det<T>(h, n, dA, ld, dp, dout));
     double out[3];
+    int hinfo = 0;
     LSX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
+    if (hinfo < 0) {   // a determinant of garbage factors must not be returned as a value
+        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
+        return LSX_ERR_INTERNAL;
+    }
     *sign = out[0]; *mant = out[1]; *exp2 = (int64_t)out[2];
     return LSX_OK;
+}
+
+template <typename T>
+static int rref_host(lsx_handle_t h, int m, int n, int bar_col, const T *A, int lda, T *R, int ldr, int32_t *pivots,
+                     int *rank, double tol, int pivot_rule) {
+    LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && rank);
+    LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
+    const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
+    LSX_ARG(bar <= n);
+    const int ld = ld_for(n);
+    const int np = m < n ? m : n;
+    LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)m * ld) + pad256(sizeof(int32_t) * 2 * np) + 512));
+    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096));
+    Carver c(h->ws);
+    T *dR = c.take<T>((size_t)m * ld);
+    int32_t *dp = c.take<int32_t>(2 * (size_t)np);
+    int *drank = c.take<int>(1);
+    LSX_TRY(h2d<T>(h, m, n, A, lda, dR, ld));
+    LSX_TRY(launch_rref<T>(h, m, n, bar, dR, ld, dp, drank, tol, pivot_rule));
+    LSX_TRY(d2h<T>(h, m, n, dR, ld, R, ldr));
+    int hr = 0;
+    LSX_HIP(hipMemcpyAsync(&hr, drank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    *rank = hr;
+    if (hr > 0) LSX_HIP(hipMemcpy(pivots, dp, sizeof(int32_t) * 2 * hr, hipMemcpyDeviceToHost));
+    return LSX_OK;
+}
+
+// Mixed-precision solve (BASELINE config 5, "tolerance 1e-4" against the fp64 result): fp32 factors, residuals
+// b - A x accumulated in fp64, `sweeps` corrections through the same factors.  dA (unfactored) and dB are read,
+// dLU (n x n, ldl) receives the factors, dX64 (n x nrhs) the solution in fp64, dX32 (may be NULL) its fp32 rounding.
+// d_stats (4 doubles, may be NULL): max|d| and max|x| of the last sweep, then of the first.  Asynchronous.
+static int gesv_refined_dev(lsx_handle_t h, int n, int nrhs, const float *dA, int lda, float *dLU, int ldl, int32_t *d_ipiv,
+                            int *d_info, const float *dB, int ldb, double *dX64, int ldx, float *dX32, int ldf, int sweeps,
+                            double *d_stats) {
+    LSX_ARG(n >= 1 && nrhs >= 1 && dA && dLU && d_ipiv && d_info && dB && dX64 && sweeps >= 0 && sweeps <= 16);
+    LSX_TRY(launch_copy2d<float>(h, n, n, dA, lda, dLU, ldl));
+    LSX_TRY(getrf_dev<float>(h, n, dLU, ldl, d_ipiv, d_info));
+    // correction / right-hand-side buffer: n x nrhs fp32 (ws3 belongs to getrs)
+    const int ldr = nrhs;
+    LSX_TRY(grow(&h->ws4, &h->ws4_bytes, sizeof(float) * (size_t)n * ldr));
+    float *dR = (float *)h->ws4;
+    int rc = launch_copy2d<float>(h, n, nrhs, dB, ldb, dR, ldr);
+    if (rc == LSX_OK) rc = getrs_dev<float>(h, n, nrhs, dLU, ldl, d_ipiv, dR, ldr);
+    if (rc == LSX_OK) rc = launch_refine_apply(h, n, nrhs, 1, dR, ldr, dX64, ldx, dX32, ldf, d_stats ? d_stats + 2 : nullptr);
+    for (int s = 0; s < sweeps && rc == LSX_OK; ++s) {
+        rc = launch_resid_mixed(h, n, nrhs, dA, lda, dB, ldb, dX64, ldx, dR, ldr);
+        if (rc == LSX_OK) rc = getrs_dev<float>(h, n, nrhs, dLU, ldl, d_ipiv, dR, ldr);
+        if (rc == LSX_OK) rc = launch_refine_apply(h, n, nrhs, 0, dR, ldr, dX64, ldx, dX32, ldf, d_stats);
+    }
+    return rc;
+}
+
+}  // namespace lsx
+
+extern "C" {
+
+int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv, int ldi, int *info,
+                  double *pivot_ratio) {
+    return getri_host<double>(h, n, A, lda, Ainv, ldi, info, pivot_ratio);
+}
+int lsx_getri_f32(lsx_handle_t h, int n, const float *A, int lda, float *Ainv, int ldi, int *info,
+                  double *pivot_ratio) {
+    return getri_host<float>(h, n, A, lda, Ainv, ldi, info, pivot_ratio);
+}
+int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, double *mant, int64_t *exp2) {
+    return det_host<double>(h, n, A, lda, sign, mant, exp2);
+}
+int lsx_det_f32(lsx_handle_t h, int n, const float *A, int lda, double *sign, double *mant, int64_t *exp2) {
+    return det_host<float>(h, n, A, lda, sign, mant, exp2);
+}
+
+// fp32 factors + fp64 residuals: X (fp32) and / or X64 (fp64) <- A^-1 B to well below the fp32 forward error
+int lsx_gesv_f32_refined(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb, float *X,
+                         int ldx, double *X64, int ldx64, int sweeps, int *info, double *pivot_ratio,
+                         double *last_correction) {
+    LSX_ARG(h && n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs && sweeps >= 0 && sweeps <= 16);
+    if (info) *info = 0;
+    if (pivot_ratio) *pivot_ratio = 1.0;
+    if (last_correction) *last_correction = 0.0;
+    if (n == 0 || nrhs == 0) return LSX_OK;
+    LSX_ARG(A && B && (X || X64) && (!X || ldx >= nrhs) && (!X64 || ldx64 >= nrhs));
+    const int ld = ld_for(n), lr = ld_for(nrhs);
+    LSX_TRY(ensure_ws(h, 2 * pad256(sizeof(float) * (size_t)n * ld) + pad256(sizeof(float) * (size_t)n * lr) * 2 +
+                             pad256(sizeof(double) * (size_t)n * lr) + pad256(sizeof(int32_t) * n) + 1024));
+    Carver c(h->ws);
+    float *dA = c.take<float>((size_t)n * ld);
+    float *dLU = c.take<float>((size_t)n * ld);
+    float *dB = c.take<float>((size_t)n * lr);
+    float *dXf = c.take<float>((size_t)n * lr);
+    double *dX = c.take<double>((size_t)n * lr);
+    int32_t *dp = c.take<int32_t>(n);
+    int *dinfo = c.take<int>(1);
+    double *dstats = c.take<double>(6);
+    LSX_TRY(h2d<float>(h, n, n, A, lda, dA, ld));
+    LSX_TRY(h2d<float>(h, n, nrhs, B, ldb, dB, lr));
+    LSX_TRY(launch_amax<float>(h, n, n, dA, ld, dstats + 4));
+    LSX_TRY(gesv_refined_dev(h, n, nrhs, dA, ld, dLU, ld, dp, dinfo, dB, lr, dX, lr, dXf, lr, sweeps, dstats));
+    LSX_TRY(launch_diag_minabs<float>(h, n, dLU, ld, dstats + 4));
+    int hinfo = 0;
+    double st[6] = {0, 0, 0, 0, 0, 0};
+    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipMemcpyAsync(st, dstats, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (info) *info = hinfo;
+    if (pivot_ratio) *pivot_ratio = st[4] > 0 ? st[5] / st[4] : 0.0;
+    if (hinfo < 0) {
+        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
+        return LSX_ERR_INTERNAL;
+    }
+    if (hinfo != 0) return LSX_OK;   // singular: X untouched
+    if (last_correction) *last_correction = st[1] > 0 ? st[0] / st[1] : 0.0;
+    if (X) LSX_TRY(d2h<float>(h, n, nrhs, dXf, lr, X, ldx));
+    if (X64) LSX_TRY(d2h<double>(h, n, nrhs, dX, lr, X64, ldx64));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    return LSX_OK;
+}
+int lsx_gesv_f32_refined_dev(lsx_handle_t h, int n, int nrhs, const float *dA, int lda, float *dLU, int ldl,
+                             int32_t *d_ipiv, int *d_info, const float *dB, int ldb, double *dX64, int ldx, float *dX32,
+                             int ldf, int sweeps, double *d_stats) {
+    LSX_ARG(h && lda >= n && ldl >= n && ldb >= nrhs && ldx >= nrhs && (!dX32 || ldf >= nrhs));
+    return gesv_refined_dev(h, n, nrhs, dA, lda, dLU, ldl, d_ipiv, d_info, dB, ldb, dX64, ldx, dX32, ldf, sweeps, d_stats);
 }
 
 int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda, const double *B, int ldb,
@@ -948,27 +1081,11 @@ int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda
 
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
                  int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
-    LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && rank);
-    LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
-    const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
-    LSX_ARG(bar <= n);
-    const int ld = ld_for(n);
-    const int np = m < n ? m : n;
-    LSX_TRY(ensure_ws(h, pad256(sizeof(double) * (size_t)m * ld) + pad256(sizeof(int32_t) * 2 * np) + 512));
-    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096));
-    Carver c(h->ws);
-    double *dR = c.take<double>((size_t)m * ld);
-    int32_t *dp = c.take<int32_t>(2 * (size_t)np);
-    int *drank = c.take<int>(1);
-    LSX_TRY(h2d<double>(h, m, n, A, lda, dR, ld));
-    LSX_TRY(launch_rref<double>(h, m, n, bar, dR, ld, dp, drank, tol, pivot_rule));
-    LSX_TRY(d2h<double>(h, m, n, dR, ld, R, ldr));
-    int hr = 0;
-    LSX_HIP(hipMemcpyAsync(&hr, drank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    LSX_HIP(hipStreamSynchronize(h->stream));
-    *rank = hr;
-    if (hr > 0) LSX_HIP(hipMemcpy(pivots, dp, sizeof(int32_t) * 2 * hr, hipMemcpyDeviceToHost));
-    return LSX_OK;
+    return rref_host<double>(h, m, n, bar_col, A, lda, R, ldr, pivots, rank, tol, pivot_rule);
+}
+int lsx_rref_f32(lsx_handle_t h, int m, int n, int bar_col, const float *A, int lda, float *R,
+                 int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
+    return rref_host<float>(h, m, n, bar_col, A, lda, R, ldr, pivots, rank, tol, pivot_rule);
 }
 
 // ---- device-pointer entry points
@@ -999,6 +1116,16 @@ int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int
                     double *d_out) {
     LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
     return launch_det<double>(h, n, dLU, lda, d_ipiv, d_out);
+}
+int lsx_getri_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv,
+                      float *dInv, int ldi) {
+    LSX_ARG(h);
+    return getri_dev<float>(h, n, dLU, lda, d_ipiv, dInv, ldi);
+}
+int lsx_det_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv,
+                    double *d_out) {
+    LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
+    return launch_det<float>(h, n, dLU, lda, d_ipiv, d_out);
 }
 int lsx_rref_trace_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R, int ldr,
                        unsigned char *int_mask, int32_t *pivots, int *npivots, int32_t *steps, int max_steps,

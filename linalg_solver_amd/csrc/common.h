@@ -101,6 +101,8 @@ struct lsx_handle_s {
     size_t ws2_bytes = 0;
     void *ws3 = nullptr;     // permutation vector + right-hand-side copy
     size_t ws3_bytes = 0;
+    void *ws4 = nullptr;     // residual / correction of the mixed-precision solve
+    size_t ws4_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
     void *moves = nullptr;      // int2[256]: gather list emitted by the cooperative panel kernel (current buffer)
     void *moves_buf[2] = {nullptr, nullptr};  // the look-ahead driver alternates between two lists
@@ -181,6 +183,10 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
 template <typename T>
 int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nsteps, const void *lists);
 int launch_gate(lsx_handle_t h, const int *word, int target);
+int launch_resid_mixed(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb, const double *X,
+                       int ldx, float *R, int ldr);
+int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *D, int ldd, double *X, int ldx, float *Xf,
+                        int ldf, double *d_out2);
 template <typename T>
 int diag_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
                     const void *moves);

@@ -1017,6 +1017,77 @@ int launch_copy2d(lsx_handle_t h, int m, int n, const T *S, int lds, T *D, int l
     return LSX_OK;
 }
 
+// ------------------------------------------------------------------ mixed-precision refinement (fp32 factors)
+// r = b - A x with A, b in fp32 and x, the products and the sum in fp64; the residual goes back in fp32 for the
+// next correction solve.  One wave per row, lanes stride the columns (coalesced 256-byte pieces of the row), up to
+// 8 right-hand sides per pass.  HBM-bound: A is read once per sweep (4 n^2 bytes).
+__global__ __launch_bounds__(256) void resid_mixed_kernel(int n, int nrhs, const float *__restrict__ A, int lda,
+                                                          const float *__restrict__ B, int ldb,
+                                                          const double *__restrict__ X, int ldx,
+                                                          float *__restrict__ R, int ldr) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *a = A + (size_t)row * lda;
+    for (int c0 = 0; c0 < nrhs; c0 += 8) {
+        double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = lane; k < n; k += 64) {
+            const double av = (double)a[k];
+            const double *x = X + (size_t)k * ldx + c0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < nrhs) part[j] = __builtin_fma(av, x[j], part[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double v = part[j];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && c0 + j < nrhs)
+                R[(size_t)row * ldr + c0 + j] = (float)((double)B[(size_t)row * ldb + c0 + j] - v);
+        }
+    }
+}
+// X (fp64) <- D (fp32) [init] or X += D; Xf <- (float) X; out[0] = max|D|, out[1] = max|X| (as ordered ints: >= 0)
+__global__ __launch_bounds__(256) void refine_apply_kernel(int n, int nrhs, int init, const float *__restrict__ D, int ldd,
+                                                           double *__restrict__ X, int ldx, float *__restrict__ Xf,
+                                                           int ldf, unsigned long long *__restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    double ad = 0, ax = 0;
+    if (idx < n * nrhs) {
+        const int i = idx / nrhs, j = idx % nrhs;
+        const double d = (double)D[(size_t)i * ldd + j];
+        const double x = init ? d : X[(size_t)i * ldx + j] + d;
+        X[(size_t)i * ldx + j] = x;
+        if (Xf) Xf[(size_t)i * ldf + j] = (float)x;
+        ad = fabs(d);
+        ax = fabs(x);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        ad = fmax(ad, __shfl_down(ad, off, 64));
+        ax = fmax(ax, __shfl_down(ax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && out) {   // non-negative doubles order like their bit patterns
+        atomicMax(&out[0], (unsigned long long)__double_as_longlong(ad));
+        atomicMax(&out[1], (unsigned long long)__double_as_longlong(ax));
+    }
+}
+int launch_resid_mixed(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb, const double *X,
+                       int ldx, float *R, int ldr) {
+    hipLaunchKernelGGL(resid_mixed_kernel, dim3((n + 3) / 4), dim3(256), 0, h->stream, n, nrhs, A, lda, B, ldb, X, ldx, R, ldr);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *D, int ldd, double *X, int ldx, float *Xf,
+                        int ldf, double *d_out2) {
+    if (d_out2) LSX_HIP(hipMemsetAsync(d_out2, 0, 2 * sizeof(double), h->stream));
+    hipLaunchKernelGGL(refine_apply_kernel, dim3((n * nrhs + 255) / 256), dim3(256), 0, h->stream, n, nrhs, init, D, ldd, X,
+                       ldx, Xf, ldf, (unsigned long long *)d_out2);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
 #define INST(T)                                                                                   \
     template int launch_fill<T>(lsx_handle_t, int, uint64_t, int, int, T *, int, int, int);       \
     template int launch_laswp<T>(lsx_handle_t, int, T *, int, int, int, const int32_t *);         \

@@ -94,36 +94,74 @@ def solve(a, b, handle: Optional[N.Handle] = None, dtype=np.float64):
     return (X[:, 0].copy() if vec else X), 0, ratio.value
 
 
-def inv(a, handle: Optional[N.Handle] = None):
+def _ct(dtype):
+    if dtype == np.float64:
+        return C.c_double, "f64"
+    if dtype == np.float32:
+        return C.c_float, "f32"
+    raise TypeError("dtype must be float64 or float32")
+
+
+def solve_refined(a, b, sweeps: int = 3, handle: Optional[N.Handle] = None):
+    """Mixed-precision solve of A X = B (lsx_gesv_f32_refined): fp32 factors on the fp32 MFMA tile, residuals in
+    fp64, `sweeps` corrections.  a and b are taken in fp32 (BASELINE config 5 computes in fp32); returns
+    (X as float64, info, pivot_ratio, last_correction) -- X is None when info != 0.  The forward error against
+    the fp64 solution of the same system is far below the 1e-4 the configuration asks for, which a plain fp32
+    solve of a large random system does not reach (cond * eps32)."""
+    h = _h(handle)
+    A = np.ascontiguousarray(a, dtype=np.float32)
+    n = A.shape[0]
+    if A.ndim != 2 or A.shape[1] != n:
+        raise ValueError("solve needs a square matrix")
+    B = np.array(b, dtype=np.float32, order="C", copy=True)
+    vec = B.ndim == 1
+    if vec:
+        B = B.reshape(n, 1).copy()
+    if B.shape[0] != n:
+        raise ValueError("right-hand side has the wrong number of rows")
+    nrhs = B.shape[1]
+    X = np.zeros((n, nrhs), dtype=np.float64)
+    info, ratio, corr = C.c_int(0), C.c_double(1.0), C.c_double(0.0)
+    N.check(h.lib.lsx_gesv_f32_refined(h.ptr, n, nrhs, _ptr(A, C.c_float), n, _ptr(B, C.c_float), nrhs, None, nrhs,
+                                       _ptr(X, C.c_double), nrhs, int(sweeps), C.byref(info), C.byref(ratio),
+                                       C.byref(corr)), "lsx_gesv_f32_refined")
+    if info.value != 0:
+        return None, info.value, ratio.value, corr.value
+    return (X[:, 0].copy() if vec else X), 0, ratio.value, corr.value
+
+
+def inv(a, handle: Optional[N.Handle] = None, dtype=np.float64):
     """Returns (inverse or None, info, pivot_ratio)."""
     h = _h(handle)
-    A = _f64(a)
+    ct, sfx = _ct(dtype)
+    A = np.ascontiguousarray(a, dtype=dtype)
     n = A.shape[0]
     if A.ndim != 2 or A.shape[1] != n:
         raise ValueError("inv needs a square matrix")
     out = np.empty_like(A)
     info, ratio = C.c_int(0), C.c_double(1.0)
-    N.check(h.lib.lsx_getri_f64(h.ptr, n, _ptr(A, C.c_double), n, _ptr(out, C.c_double), n, C.byref(info),
-                                C.byref(ratio)), "lsx_getri_f64")
+    N.check(getattr(h.lib, f"lsx_getri_{sfx}")(h.ptr, n, _ptr(A, ct), n, _ptr(out, ct), n, C.byref(info),
+                                                C.byref(ratio)), f"lsx_getri_{sfx}")
     if info.value != 0:
         return None, info.value, ratio.value
     return out, 0, ratio.value
 
 
-def det_parts(a, handle: Optional[N.Handle] = None) -> Tuple[float, float, int]:
+def det_parts(a, handle: Optional[N.Handle] = None, dtype=np.float64) -> Tuple[float, float, int]:
     """det(A) = sign * mant * 2**exp2 with mant in [0.5, 1) (sign 0 for a singular matrix)."""
     h = _h(handle)
-    A = _f64(a)
+    ct, sfx = _ct(dtype)
+    A = np.ascontiguousarray(a, dtype=dtype)
     n = A.shape[0]
     if A.ndim != 2 or A.shape[1] != n:
         raise ValueError("det needs a square matrix")
     s, m, e = C.c_double(0), C.c_double(0), C.c_int64(0)
-    N.check(h.lib.lsx_det_f64(h.ptr, n, _ptr(A, C.c_double), n, C.byref(s), C.byref(m), C.byref(e)), "lsx_det_f64")
+    N.check(getattr(h.lib, f"lsx_det_{sfx}")(h.ptr, n, _ptr(A, ct), n, C.byref(s), C.byref(m), C.byref(e)), f"lsx_det_{sfx}")
     return s.value, m.value, int(e.value)
 
 
-def slogdet(a, handle: Optional[N.Handle] = None) -> Tuple[float, float]:
-    s, m, e = det_parts(a, handle)
+def slogdet(a, handle: Optional[N.Handle] = None, dtype=np.float64) -> Tuple[float, float]:
+    s, m, e = det_parts(a, handle, dtype)
     if s == 0.0:
         return 0.0, -math.inf
     return s, math.log(m) + e * math.log(2.0)
@@ -155,19 +193,21 @@ def matmul(a, b, handle: Optional[N.Handle] = None) -> np.ndarray:
 
 
 def rref(a, bar_col: Optional[int] = None, tol: float = -1.0, handle: Optional[N.Handle] = None,
-         pivot_rule: int = N.PIVOT_FIRST):
+         pivot_rule: int = N.PIVOT_FIRST, dtype=np.float64):
     """Reduced row echelon form over columns [0, bar_col).  Returns (R, pivots, rank).
     pivot_rule: N.PIVOT_FIRST = the reference's first-non-zero rule, N.PIVOT_MAX = largest |a|."""
     h = _h(handle)
-    A = _f64(a)
+    ct, sfx = _ct(dtype)
+    A = np.ascontiguousarray(a, dtype=dtype)
     if A.ndim != 2 or A.shape[0] < 1 or A.shape[1] < 1:
         raise ValueError("rref needs a non-empty 2-D matrix")
     m, n = A.shape
     R = np.empty_like(A)
     piv = np.zeros(2 * min(m, n), dtype=np.int32)
     rank = C.c_int(0)
-    N.check(h.lib.lsx_rref_f64(h.ptr, m, n, int(bar_col or 0), _ptr(A, C.c_double), n, _ptr(R, C.c_double), n,
-                               _ptr(piv, C.c_int32), C.byref(rank), float(tol), int(pivot_rule)), "lsx_rref_f64")
+    N.check(getattr(h.lib, f"lsx_rref_{sfx}")(h.ptr, m, n, int(bar_col or 0), _ptr(A, ct), n, _ptr(R, ct), n,
+                                               _ptr(piv, C.c_int32), C.byref(rank), float(tol), int(pivot_rule)),
+            f"lsx_rref_{sfx}")
     r = rank.value
     return R, [(int(piv[2 * i]), int(piv[2 * i + 1])) for i in range(r)], r
 

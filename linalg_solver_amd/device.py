@@ -75,16 +75,37 @@ class DeviceSolver:
         n = LU.shape[0]
         if out is None:
             out = torch.empty(n, n, dtype=LU.dtype, device=LU.device)
-        N.check(self.lib.lsx_getri_f64_dev(self.h.ptr, n, LU.data_ptr(), LU.stride(0), ipiv.data_ptr(),
-                                           out.data_ptr(), out.stride(0)), "getri_dev")
+        fn = getattr(self.lib, f"lsx_getri_{self._suffix(LU)}_dev")
+        N.check(fn(self.h.ptr, n, LU.data_ptr(), LU.stride(0), ipiv.data_ptr(), out.data_ptr(), out.stride(0)), "getri_dev")
         return out
 
     def det_parts(self, LU: torch.Tensor, ipiv: torch.Tensor) -> torch.Tensor:
         """Device tensor [sign, mant, exp2]."""
         out = torch.empty(3, dtype=torch.float64, device=LU.device)
-        N.check(self.lib.lsx_det_f64_dev(self.h.ptr, LU.shape[0], LU.data_ptr(), LU.stride(0), ipiv.data_ptr(),
-                                         out.data_ptr()), "det_dev")
+        fn = getattr(self.lib, f"lsx_det_{self._suffix(LU)}_dev")
+        N.check(fn(self.h.ptr, LU.shape[0], LU.data_ptr(), LU.stride(0), ipiv.data_ptr(), out.data_ptr()), "det_dev")
         return out
+
+    def gesv_refined(self, A: torch.Tensor, B: torch.Tensor, sweeps: int = 3):
+        """Mixed-precision solve on tensors in HBM: A (n x n fp32, kept), B (n x nrhs fp32, kept).  Returns
+        (X fp64, X fp32, LU fp32, ipiv, info, stats) -- stats = [max|d|, max|x|] of the last sweep, then of the
+        unrefined solve (device tensor, 4 doubles).  lsx_gesv_f32_refined_dev; asynchronous."""
+        _rowmajor(A, "gesv_refined")
+        _rowmajor(B, "gesv_refined")
+        if A.dtype != torch.float32 or B.dtype != torch.float32:
+            raise TypeError("gesv_refined takes fp32 operands")
+        n, nrhs = A.shape[0], B.shape[1]
+        LU = torch.empty(n, n, dtype=torch.float32, device=A.device)
+        X64 = torch.empty(n, nrhs, dtype=torch.float64, device=A.device)
+        X32 = torch.empty(n, nrhs, dtype=torch.float32, device=A.device)
+        ipiv = torch.empty(max(n, 1), dtype=torch.int32, device=A.device)
+        info = torch.zeros(1, dtype=torch.int32, device=A.device)
+        stats = torch.zeros(4, dtype=torch.float64, device=A.device)
+        N.check(self.lib.lsx_gesv_f32_refined_dev(self.h.ptr, n, nrhs, A.data_ptr(), A.stride(0), LU.data_ptr(), n,
+                                                  ipiv.data_ptr(), info.data_ptr(), B.data_ptr(), B.stride(0),
+                                                  X64.data_ptr(), nrhs, X32.data_ptr(), nrhs, int(sweeps),
+                                                  stats.data_ptr()), "gesv_refined_dev")
+        return X64, X32, LU, ipiv, info, stats
 
     def gemm_sub_(self, C: torch.Tensor, A: torch.Tensor, B: torch.Tensor):
         """C -= A @ B on the MFMA kernel."""

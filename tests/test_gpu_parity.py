@@ -828,3 +828,85 @@ def test_chain_head_fused_equals_separate(la, dtype, jb, ld, ncols):
         if d >= 0:
             exp[d, :ncols] = src[s_, :ncols]
     assert torch.equal(As[1], exp) and torch.equal(As[0], A0)
+
+
+@pytest.mark.parametrize("n", [64, 300, 1024])
+def test_fp32_solve_refined_matches_the_fp64_oracle_to_1e4(la, n):
+    """BASELINE config 5, to the letter: the fp32 path's SOLUTION within 1e-4 of the fp64 result.  Factors in fp32,
+    residuals in fp64 (lsx_gesv_f32_refined); the oracle is the CPU twin in fp64 on the same (fp32-valued) system.
+    The unrefined fp32 solve is reported beside it: it is the one that cannot promise 1e-4 (cond * eps32)."""
+    from linalg_solver_amd import dense, gen
+
+    A, b = gen.system(gen.U11, 900 + n, n)
+    A32, b32 = A.astype(np.float32), b.astype(np.float32)
+    A64, b64 = A32.astype(np.float64), b32.astype(np.float64)
+    oLU, oipiv, oinfo = capi.getrf(A64)
+    xo = capi.getrs(oLU, oipiv, b64)
+    x, info, ratio, corr = dense.solve_refined(A32, b32, sweeps=3)
+    x0, info0, _ = dense.solve(A32, b32, dtype=np.float32)
+    assert info == 0 and info0 == 0 and oinfo == 0
+    err = relerr(x, xo)
+    err0 = relerr(x0.astype(np.float64), xo)
+    print(f"n={n}: forward error refined {err:.2e}, unrefined {err0:.2e}, last correction {corr:.2e}")
+    assert err < 1e-9, err          # fp64-residual refinement converges to the fp64 solution itself
+    assert err < TOL32 and corr < 1e-6
+    assert err <= err0
+
+
+def test_fp32_inverse_determinant_and_rank(la):
+    """lsx_getri_f32 / lsx_det_f32 / lsx_rref_f32 (SURVEY 8b lists the callers for both precisions)."""
+    from linalg_solver_amd import dense, gen
+
+    n = 200
+    A, _ = gen.system(gen.U11, 77, n)
+    A32 = A.astype(np.float32)
+    Ai, info, _ = dense.inv(A32, dtype=np.float32)
+    assert info == 0 and Ai.dtype == np.float32
+    assert np.max(np.abs(A32.astype(np.float64) @ Ai.astype(np.float64) - np.eye(n))) < 5e-3
+    Ai64, _, _ = dense.inv(A32.astype(np.float64))
+    assert relerr(Ai.astype(np.float64), Ai64) < 5e-3
+    s32, l32 = dense.slogdet(A32, dtype=np.float32)
+    s64, l64 = np.linalg.slogdet(A32.astype(np.float64))
+    assert s32 == s64 and abs(l32 - l64) < 1e-3 * max(1.0, abs(l64))
+    # rank: a rank-5 product, fp32 entries
+    rng = np.random.default_rng(3)
+    M = (rng.integers(-3, 4, (12, 5)) @ rng.integers(-3, 4, (5, 9))).astype(np.float32)
+    R, piv, r = dense.rref(M, bar_col=9, dtype=np.float32, pivot_rule=la._native.PIVOT_MAX)
+    assert r == np.linalg.matrix_rank(M.astype(np.float64)) == 5 and R.dtype == np.float32
+    R64, piv64, r64 = dense.rref(M.astype(np.float64), bar_col=9, pivot_rule=la._native.PIVOT_MAX)
+    assert piv == piv64 and relerr(R.astype(np.float64), R64) < 1e-4
+
+
+def test_full_size_fp32_solution_within_1e4_of_the_fp64_solution(dev):
+    """config 5 at its own size: 8192 x 8192 fp32 factors, 4 right-hand sides; the refined solution against the
+    fp64 GPU solution of the same system (which test_full_size_lu_invariants holds to a 1e-9 backward error)."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    n, nrhs = 8192, 4
+    A = torch.empty(n, n, dtype=torch.float32, device="cuda")
+    B = torch.empty(n, nrhs, dtype=torch.float32, device="cuda")
+    dev.fill_(A, gen.U11, 1)
+    dev.fill_(B, gen.U11, 2)
+    X64, X32, LU32, ipiv32, info, stats = dev.gesv_refined(A, B, sweeps=3)
+    A64 = A.double()
+    X = B.double().clone()
+    ipiv, info64 = dev.getrf_(A64)
+    dev.getrs_(A64, ipiv, X)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0 and int(info64.item()) == 0
+    st = stats.cpu().numpy()
+    # the unrefined fp32 solve, from the same factors
+    X0 = B.clone()
+    dev.getrs_(LU32, ipiv32, X0)
+    torch.cuda.synchronize()
+    scale = float(X.abs().max())
+    err = float((X64 - X).abs().max()) / scale
+    err32 = float((X32.double() - X).abs().max()) / scale
+    err0 = float((X0.double() - X).abs().max()) / scale
+    print(f"8192 fp32: forward error refined {err:.2e} (rounded to fp32 {err32:.2e}), unrefined {err0:.2e}; "
+          f"last correction {st[0] / st[1]:.2e}")
+    # three sweeps gain about two digits each here (cond * eps32 ~ 1e-2): 9e-3 -> 6e-9 measured
+    assert err < 1e-6 and err32 < 1e-6 < TOL32 and err0 > err32
+    assert st[0] / st[1] < 1e-5
