@@ -23,7 +23,7 @@
  *   - Host-buffer entry points copy to the device, compute there and copy back.
  *     The *_dev entry points work on device pointers already resident in HBM and
  *     are asynchronous on the handle's stream.
- *   - One handle = one GPU = one host thread at a time.  Handles are independent.
+ *   - One handle = one GPU = one host thread at a time.  Handles are independent (every call makes the handle's device current for its duration and restores the caller's).
  *   - There is NO CPU fallback: without a usable gfx950 device lsx_create fails.
  */
 #ifndef LSX_H
@@ -86,6 +86,12 @@ const char *lsx_last_error(void);
  * "gemm_waves", "gemm_stagger", "panel_rt", "panel_nt", "trsv" (few-RHS solve: 1 = one cooperative launch
  * per direction [default], 0 = one launch per 128-row step).  Returns LSX_ERR_ARG for unknown keys. */
 int lsx_set_option(lsx_handle_t h, const char *key, int value);
+/* The cooperative kernels (panel pivot exchange, few-right-hand-side solve) poll each other with a bounded spin; a
+ * time-out -- their workgroups were not all resident, e.g. another kernel held the CUs -- is recorded in a device
+ * word.  The host-buffer entry points check it themselves and return LSX_ERR_INTERNAL instead of a result; after
+ * *_dev calls (asynchronous, no info word required) this synchronises the handle's stream and reports it:
+ * LSX_OK, or LSX_ERR_INTERNAL once (the word is cleared). */
+int lsx_check_status(lsx_handle_t h);
 int lsx_get_option(lsx_handle_t h, const char *key, int *value);
 
 /* ---- host-buffer entry points (fp64) ------------------------------------ */

@@ -37,6 +37,7 @@ _SIGS = {
     "lsx_use_own_stream": [_vp],
     "lsx_synchronize": [_vp],
     "lsx_set_option": [_vp, C.c_char_p, _i],
+    "lsx_check_status": [_vp],
     "lsx_get_option": [_vp, C.c_char_p, C.POINTER(_i)],
     "lsx_getrf_f64": [_vp, _i, _dp, _i, _ip, C.POINTER(_i)],
     "lsx_getrs_f64": [_vp, _i, _i, _dp, _i, _ip, _dp, _i],
@@ -175,6 +176,10 @@ class Handle:
 
     def use_own_stream(self):
         check(self.lib.lsx_use_own_stream(self._h), "lsx_use_own_stream")
+
+    def check_status(self):
+        """Synchronise and raise LsxError if a cooperative kernel timed out since the last check (lsx_check_status)."""
+        check(self.lib.lsx_check_status(self._h), "lsx_check_status")
 
     def synchronize(self):
         check(self.lib.lsx_synchronize(self._h), "lsx_synchronize")

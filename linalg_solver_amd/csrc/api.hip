@@ -39,6 +39,34 @@ static int grow(void **p, size_t *have, size_t need) {
 
 int ensure_ws(lsx_handle_t h, size_t bytes) { return grow(&h->ws, &h->ws_bytes, bytes); }
 
+// Every entry point runs with the handle's device current and puts the caller's back on the way out: with two
+// handles in one process, or torch's current device elsewhere, workspaces and launches would land on the wrong GPU.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(lsx_handle_t h) {
+        if (!h) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+#define LSX_DEVICE_GUARD(h) lsx::DeviceGuard device_guard_(h)
+
+// The cooperative kernels (panel exchange, few-RHS solve) give up after a bounded spin and say so in a device word;
+// a host-buffer entry point must not hand back what was computed after that.  Synchronises the handle's stream.
+static int check_dev_status(lsx_handle_t h) {
+    int st[3] = {0, 0, 0};
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    LSX_HIP(hipMemcpy(st, h->dev_status, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[0] == 0 && st[1] == 0 && st[2] >= 0) return LSX_OK;
+    LSX_HIP(hipMemset(h->dev_status, 0, sizeof(st)));
+    set_error("%s timed out on the device (its workgroups were not all resident: another kernel holding the CUs?)",
+              st[1] ? "the cooperative triangular solve" : "the panel exchange");
+    return LSX_ERR_INTERNAL;
+}
+
 static int ensure_scratch(lsx_handle_t h, size_t bytes) {
     // growing frees the old block: make sure nothing queued still uses it
     if (bytes > h->scratch_bytes) LSX_HIP(hipStreamSynchronize(h->stream));
@@ -147,7 +175,10 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         const int G = (n - k0 + 32 * slice_rt - 1) / (32 * slice_rt);
         int pcus = ((G + G / 2 + 31) / 32) * 32;
         if (pcus > h->num_cu / 2) pcus = h->num_cu / 2;
-        if (const char *e = getenv("LSX_PANEL_CUS")) pcus = atoi(e);  // diagnostics: force the split
+        if (const char *e = getenv("LSX_PANEL_CUS")) {   // diagnostics: force the split (kept inside the chip)
+            const int v = atoi(e);
+            if (v >= 1 && v <= h->num_cu / 2) pcus = v;
+        }
         if (pcus < G) {
             partitioned = false;   // the panel does not fit in half the chip: plain look-ahead
         } else {
@@ -407,7 +438,8 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * sizeof(T))));   // x2: the look-ahead driver alternates
     T *Tinv = (T *)h->ws2;
-    if (d_info) LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
+    if (!d_info) d_info = h->dev_status + 2;   // a time-out must be recorded somewhere: lsx_check_status reads it
+    LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));
     // Look-ahead (panel k+1 on a side stream under the update of step k; bit-identical factors).  Measured
     // on MI355X with the pipelined panel, lookahead=1 against the sequential driver: n = 4096 -8 %,
     // 6144 +0.5 %, 7168 +5 %, 8192 +8 %, 10240..16384 +11..12 %, 20480 +10 %.  Below ~6500 the shorter update
@@ -415,7 +447,10 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 10240;   // fp32: the update is half as long, break-even higher
     if (h->panel_mode == 4) LOOKAHEAD_MIN = sizeof(T) == 8 ? 3072 : 4096;   // XCD-scope panel and its own schedule
     if (h->lookahead_min > 0) LOOKAHEAD_MIN = h->lookahead_min;                  // option (tests, tuning)
-    if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) LOOKAHEAD_MIN = atoi(e);  // diagnostics
+    if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) {   // diagnostics
+        const int v = atoi(e);
+        if (v > 0) LOOKAHEAD_MIN = v;
+    }
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
     if (h->lookahead && n >= LOOKAHEAD_MIN && h->kblock == 1) k_end = 0;
     // lookahead = 1 / 3: both streams on all CUs; 2: on disjoint CU sets.  For ONE fp32 factorisation the
@@ -622,6 +657,7 @@ static int getrs_host(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, con
     LSX_TRY(h2d<T>(h, n, nrhs, B, ldb, dB, ldx));
     LSX_HIP(hipMemcpyAsync(dp, ipiv, sizeof(int32_t) * n, hipMemcpyHostToDevice, h->stream));
     LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
+    LSX_TRY(check_dev_status(h));
     LSX_TRY(d2h<T>(h, n, nrhs, dB, ldx, B, ldb));
     LSX_HIP(hipStreamSynchronize(h->stream));
     return LSX_OK;
@@ -662,6 +698,7 @@ static int gesv_host(lsx_handle_t h, int n, int nrhs, const T *A, int lda, T *B,
     }
     if (hinfo != 0 || nrhs == 0) return LSX_OK;  // singular: B is left untouched
     LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
+    LSX_TRY(check_dev_status(h));
     LSX_TRY(d2h<T>(h, n, nrhs, dB, ldx, B, ldb));
     LSX_HIP(hipStreamSynchronize(h->stream));
     return LSX_OK;
@@ -697,6 +734,11 @@ int lsx_create(lsx_handle_t *out, int device) {
         set_error("device %d is %s; liblsx is built for gfx950 (MI355X) only", device, prop.gcnArchName);
         return LSX_ERR_NODEVICE;
     }
+    struct RestoreDevice {   // the caller's (and torch's) current device is not ours to change
+        int prev = -1;
+        RestoreDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+        ~RestoreDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } restore_device;
     LSX_HIP(hipSetDevice(device));
     lsx_handle_t h = new lsx_handle_s();
     h->device = device;
@@ -724,6 +766,13 @@ int lsx_create(lsx_handle_t *out, int device) {
     }
     int r = grow(&h->scratch, &h->scratch_bytes, 1 << 20);
     if (r == LSX_OK) {
+        size_t ds = 0;
+        void *p = nullptr;
+        r = grow(&p, &ds, 256);
+        h->dev_status = (int *)p;
+        if (r == LSX_OK && hipMemset(p, 0, 256) != hipSuccess) r = LSX_ERR_HIP;
+    }
+    if (r == LSX_OK) {
         size_t mv = 0;
         r = grow(&h->moves_buf[0], &mv, 8192);
         h->moves_buf[1] = (char *)h->moves_buf[0] + 4096;
@@ -736,7 +785,7 @@ int lsx_create(lsx_handle_t *out, int device) {
 
 int lsx_destroy(lsx_handle_t h) {
     if (!h) return LSX_OK;
-    (void)hipSetDevice(h->device);
+    LSX_DEVICE_GUARD(h);
     (void)hipStreamSynchronize(h->stream);
     for (auto &ev : h->prof.pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     for (auto &e : h->prof.pool) (void)hipEventDestroy(e);
@@ -747,6 +796,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->moves_buf[0]) (void)hipFree(h->moves_buf[0]);
     if (h->moves_all) (void)hipFree(h->moves_all);
+    if (h->dev_status) (void)hipFree(h->dev_status);
     if (h->ev_panel) (void)hipEventDestroy(h->ev_panel);
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
@@ -760,6 +810,7 @@ int lsx_destroy(lsx_handle_t h) {
 }
 
 int lsx_set_stream(lsx_handle_t h, void *hip_stream) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     LSX_HIP(hipStreamSynchronize(h->stream));
     h->stream = (hipStream_t)hip_stream;  // NULL = the default (null) stream
@@ -767,6 +818,7 @@ int lsx_set_stream(lsx_handle_t h, void *hip_stream) {
 }
 
 int lsx_use_own_stream(lsx_handle_t h) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     LSX_HIP(hipStreamSynchronize(h->stream));
     h->stream = h->own_stream;
@@ -774,12 +826,20 @@ int lsx_use_own_stream(lsx_handle_t h) {
 }
 
 int lsx_synchronize(lsx_handle_t h) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     LSX_HIP(hipStreamSynchronize(h->stream));
     return LSX_OK;
 }
 
+int lsx_check_status(lsx_handle_t h) {
+    LSX_ARG(h);
+    LSX_DEVICE_GUARD(h);
+    return check_dev_status(h);
+}
+
 int lsx_set_option(lsx_handle_t h, const char *key, int value) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && key);
     if (!strcmp(key, "nb")) {
         LSX_ARG(value >= 16 && value <= 128 && value % 16 == 0);
@@ -805,6 +865,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_nt")) {
         LSX_ARG(value == 0 || value == 256 || value == 512 || value == 1024);
         h->panel_nt = value;
+    } else if (!strcmp(key, "trsv_spin_limit")) {   // tests: 0 makes the first unanswered poll a time-out
+        LSX_ARG(value >= 0);
+        h->spin_limit = value;
     } else if (!strcmp(key, "panel_xcd")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_xcd = value;
@@ -824,6 +887,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
 }
 
 int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && key && value);
     if (!strcmp(key, "nb")) *value = h->nb;
     else if (!strcmp(key, "panel")) *value = h->panel_mode;
@@ -843,25 +907,31 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
 
 // ---- fp64 host
 int lsx_getrf_f64(lsx_handle_t h, int n, double *A, int lda, int32_t *ipiv, int *info) {
+    LSX_DEVICE_GUARD(h);
     return getrf_host<double>(h, n, A, lda, ipiv, info);
 }
 int lsx_getrs_f64(lsx_handle_t h, int n, int nrhs, const double *LU, int lda, const int32_t *ipiv,
                   double *B, int ldb) {
+    LSX_DEVICE_GUARD(h);
     return getrs_host<double>(h, n, nrhs, LU, lda, ipiv, B, ldb);
 }
 int lsx_gesv_f64(lsx_handle_t h, int n, int nrhs, const double *A, int lda, double *B, int ldb,
                  int *info, double *pivot_ratio) {
+    LSX_DEVICE_GUARD(h);
     return gesv_host<double>(h, n, nrhs, A, lda, B, ldb, info, pivot_ratio);
 }
 int lsx_getrf_f32(lsx_handle_t h, int n, float *A, int lda, int32_t *ipiv, int *info) {
+    LSX_DEVICE_GUARD(h);
     return getrf_host<float>(h, n, A, lda, ipiv, info);
 }
 int lsx_getrs_f32(lsx_handle_t h, int n, int nrhs, const float *LU, int lda, const int32_t *ipiv,
                   float *B, int ldb) {
+    LSX_DEVICE_GUARD(h);
     return getrs_host<float>(h, n, nrhs, LU, lda, ipiv, B, ldb);
 }
 int lsx_gesv_f32(lsx_handle_t h, int n, int nrhs, const float *A, int lda, float *B, int ldb,
                  int *info, double *pivot_ratio) {
+    LSX_DEVICE_GUARD(h);
     return gesv_host<float>(h, n, nrhs, A, lda, B, ldb, info, pivot_ratio);
 }
 
@@ -991,16 +1061,20 @@ extern "C" {
 
 int lsx_getri_f64(lsx_handle_t h, int n, const double *A, int lda, double *Ainv, int ldi, int *info,
                   double *pivot_ratio) {
+    LSX_DEVICE_GUARD(h);
     return getri_host<double>(h, n, A, lda, Ainv, ldi, info, pivot_ratio);
 }
 int lsx_getri_f32(lsx_handle_t h, int n, const float *A, int lda, float *Ainv, int ldi, int *info,
                   double *pivot_ratio) {
+    LSX_DEVICE_GUARD(h);
     return getri_host<float>(h, n, A, lda, Ainv, ldi, info, pivot_ratio);
 }
 int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, double *mant, int64_t *exp2) {
+    LSX_DEVICE_GUARD(h);
     return det_host<double>(h, n, A, lda, sign, mant, exp2);
 }
 int lsx_det_f32(lsx_handle_t h, int n, const float *A, int lda, double *sign, double *mant, int64_t *exp2) {
+    LSX_DEVICE_GUARD(h);
     return det_host<float>(h, n, A, lda, sign, mant, exp2);
 }
 
@@ -1008,6 +1082,7 @@ int lsx_det_f32(lsx_handle_t h, int n, const float *A, int lda, double *sign, do
 int lsx_gesv_f32_refined(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb, float *X,
                          int ldx, double *X64, int ldx64, int sweeps, int *info, double *pivot_ratio,
                          double *last_correction) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && n >= 0 && nrhs >= 0 && lda >= n && ldb >= nrhs && sweeps >= 0 && sweeps <= 16);
     if (info) *info = 0;
     if (pivot_ratio) *pivot_ratio = 1.0;
@@ -1043,6 +1118,7 @@ int lsx_gesv_f32_refined(lsx_handle_t h, int n, int nrhs, const float *A, int ld
         return LSX_ERR_INTERNAL;
     }
     if (hinfo != 0) return LSX_OK;   // singular: X untouched
+    LSX_TRY(check_dev_status(h));
     if (last_correction) *last_correction = st[1] > 0 ? st[0] / st[1] : 0.0;
     if (X) LSX_TRY(d2h<float>(h, n, nrhs, dXf, lr, X, ldx));
     if (X64) LSX_TRY(d2h<double>(h, n, nrhs, dX, lr, X64, ldx64));
@@ -1052,12 +1128,14 @@ int lsx_gesv_f32_refined(lsx_handle_t h, int n, int nrhs, const float *A, int ld
 int lsx_gesv_f32_refined_dev(lsx_handle_t h, int n, int nrhs, const float *dA, int lda, float *dLU, int ldl,
                              int32_t *d_ipiv, int *d_info, const float *dB, int ldb, double *dX64, int ldx, float *dX32,
                              int ldf, int sweeps, double *d_stats) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && lda >= n && ldl >= n && ldb >= nrhs && ldx >= nrhs && (!dX32 || ldf >= nrhs));
     return gesv_refined_dev(h, n, nrhs, dA, lda, dLU, ldl, d_ipiv, d_info, dB, ldb, dX64, ldx, dX32, ldf, sweeps, d_stats);
 }
 
 int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda, const double *B, int ldb,
                    double *C, int ldc) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && m >= 0 && n >= 0 && k >= 0 && lda >= k && ldb >= n && ldc >= n);
     if (m == 0 || n == 0) return LSX_OK;
     LSX_ARG(C && (k == 0 || (A && B)));
@@ -1081,55 +1159,66 @@ int lsx_matmul_f64(lsx_handle_t h, int m, int n, int k, const double *A, int lda
 
 int lsx_rref_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R,
                  int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
+    LSX_DEVICE_GUARD(h);
     return rref_host<double>(h, m, n, bar_col, A, lda, R, ldr, pivots, rank, tol, pivot_rule);
 }
 int lsx_rref_f32(lsx_handle_t h, int m, int n, int bar_col, const float *A, int lda, float *R,
                  int ldr, int32_t *pivots, int *rank, double tol, int pivot_rule) {
+    LSX_DEVICE_GUARD(h);
     return rref_host<float>(h, m, n, bar_col, A, lda, R, ldr, pivots, rank, tol, pivot_rule);
 }
 
 // ---- device-pointer entry points
 int lsx_getrf_f64_dev(lsx_handle_t h, int n, double *dA, int lda, int32_t *d_ipiv, int *d_info) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getrf_dev<double>(h, n, dA, lda, d_ipiv, d_info);
 }
 int lsx_getrf_f32_dev(lsx_handle_t h, int n, float *dA, int lda, int32_t *d_ipiv, int *d_info) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getrf_dev<float>(h, n, dA, lda, d_ipiv, d_info);
 }
 int lsx_getrs_f64_dev(lsx_handle_t h, int n, int nrhs, const double *dLU, int lda,
                       const int32_t *d_ipiv, double *dB, int ldb) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getrs_dev<double>(h, n, nrhs, dLU, lda, d_ipiv, dB, ldb);
 }
 int lsx_getrs_f32_dev(lsx_handle_t h, int n, int nrhs, const float *dLU, int lda,
                       const int32_t *d_ipiv, float *dB, int ldb) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getrs_dev<float>(h, n, nrhs, dLU, lda, d_ipiv, dB, ldb);
 }
 int lsx_getri_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
                       double *dInv, int ldi) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getri_dev<double>(h, n, dLU, lda, d_ipiv, dInv, ldi);
 }
 int lsx_det_f64_dev(lsx_handle_t h, int n, const double *dLU, int lda, const int32_t *d_ipiv,
                     double *d_out) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
     return launch_det<double>(h, n, dLU, lda, d_ipiv, d_out);
 }
 int lsx_getri_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv,
                       float *dInv, int ldi) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     return getri_dev<float>(h, n, dLU, lda, d_ipiv, dInv, ldi);
 }
 int lsx_det_f32_dev(lsx_handle_t h, int n, const float *dLU, int lda, const int32_t *d_ipiv,
                     double *d_out) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && n >= 1 && dLU && d_ipiv && d_out);
     return launch_det<float>(h, n, dLU, lda, d_ipiv, d_out);
 }
 int lsx_rref_trace_f64(lsx_handle_t h, int m, int n, int bar_col, const double *A, int lda, double *R, int ldr,
                        unsigned char *int_mask, int32_t *pivots, int *npivots, int32_t *steps, int max_steps,
                        int *nsteps, double *snaps, unsigned char *snap_int_mask, int max_snaps) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && m >= 1 && n >= 1 && lda >= n && ldr >= n && A && R && pivots && npivots && steps && nsteps);
     LSX_ARG(max_steps >= 1 && max_snaps >= 0 && (max_snaps == 0 || (snaps && snap_int_mask)));
     const int bar = bar_col > 0 ? bar_col : n - 1;  // linalg.py:543
@@ -1170,6 +1259,7 @@ int lsx_rref_trace_f64(lsx_handle_t h, int m, int n, int bar_col, const double *
 }
 int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int ldr,
                      int32_t *d_pivots, int *d_rank, double tol, int pivot_rule) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && m >= 1 && n >= 1 && ldr >= n && dR && d_pivots);
     LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
     const int bar = bar_col > 0 ? bar_col : n - 1;
@@ -1180,16 +1270,19 @@ int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int 
 
 int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,
                       int *d_info) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && m >= 1 && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 32 + 2) * 5248 + 8192));
     return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
 }
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,
                       const int32_t *d_ipiv) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && d_ipiv && jb >= 0 && jb <= 256);
     return launch_laswp<double>(h, ncols, dA, lda, row0, jb, d_ipiv);
 }
 int lsx_panel_moves_dev(lsx_handle_t h, int32_t *d_moves, int *valid) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && d_moves && valid);
     *valid = h->moves_valid ? 1 : 0;
     if (h->moves_valid)
@@ -1197,6 +1290,7 @@ int lsx_panel_moves_dev(lsx_handle_t h, int32_t *d_moves, int *valid) {
     return LSX_OK;
 }
 int lsx_laswp_moves_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, const int32_t *d_moves) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && d_moves);
     void *keep = h->moves;
     h->moves = (void *)d_moves;
@@ -1206,6 +1300,7 @@ int lsx_laswp_moves_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int 
 }
 int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int ldl, double *dB,
                         int ldb) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dL && dB && jb >= 1 && jb <= 256);
     const size_t tinv = (size_t)((jb + 63) / 64) * 4096 * sizeof(double);
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, pad256(tinv)));
@@ -1214,32 +1309,38 @@ int lsx_trsm_lu_f64_dev(lsx_handle_t h, int jb, int ncols, const double *dL, int
 }
 int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
                          const double *dB, int ldb, double *dC, int ldc) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
     return launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
 }
 int lsx_gemm_add_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,
                          const double *dB, int ldb, double *dC, int ldc) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
     return launch_gemm_acc<double>(h, 1, m, n, k, dA, lda, dB, ldb, dC, ldc);
 }
 int lsx_gemm_sub_f32_dev(lsx_handle_t h, int m, int n, int k, const float *dA, int lda,
                          const float *dB, int ldb, float *dC, int ldc) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
     return launch_gemm_sub<float>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
 }
 
 int lsx_fill_f64_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, double *dA, int lda,
                      int row_off, int col_off) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
     return launch_fill<double>(h, kind, seed, m, n, dA, lda, row_off, col_off);
 }
 int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, float *dA, int lda,
                      int row_off, int col_off) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && lda >= n && (kind == LSX_FILL_INT5 || kind == LSX_FILL_U11));
     return launch_fill<float>(h, kind, seed, m, n, dA, lda, row_off, col_off);
 }
 
 int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dst && offset + bytes <= h->scratch_bytes);
     LSX_HIP(hipStreamSynchronize(h->stream));
     LSX_HIP(hipMemcpy(dst, (char *)h->scratch + offset, bytes, hipMemcpyDeviceToHost));
@@ -1248,18 +1349,21 @@ int lsx_diag_read_scratch(lsx_handle_t h, size_t offset, void *dst, size_t bytes
 
 int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops,
                        double *clock_mhz) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && tflops && iters > 0 && blocks_per_cu >= 1 && blocks_per_cu <= 8);
     return diag_mfma_peak(h, is_f32, iters, blocks_per_cu, tflops, clock_mhz);
 }
 
 int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_through, int epochs,
                         double *us_per_epoch, int *xcc_ids, int *nfail) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && us_per_epoch && nfail && G >= 2 && G <= 64 && (stride == 1 || stride == 8) && epochs >= 1);
     LSX_ARG(mode >= 0 && mode <= 2 && (G - 1) * stride + 1 <= 8 * h->num_cu);
     return diag_xchg_probe(h, mode, G, stride, write_through, epochs, us_per_epoch, xcc_ids, nfail);
 }
 
 int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && out && nblocks >= 1 && nwords >= 0 && (nwords == 0 || mask_words));
     return diag_cu_mask_probe(h, mask_words, nwords, nblocks, out);
 }
@@ -1268,6 +1372,7 @@ int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nword
 // of 64 x 64.  d_moves: 256 int2 (dst, src), -1 = void.  Asynchronous on the handle's stream.
 int lsx_diag_chain_head_f32(lsx_handle_t h, int fused, int jb, const float *dT, int ldt, float *dTinv, int ncols,
                             float *dA, int lda, int row0, const int32_t *d_moves) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dT && dTinv && jb >= 1 && jb <= 128);
     if (!fused) return launch_trtri<float>(h, 1, jb, dT, ldt, dTinv);
     LSX_ARG(dA && d_moves);
@@ -1275,6 +1380,7 @@ int lsx_diag_chain_head_f32(lsx_handle_t h, int fused, int jb, const float *dT, 
 }
 int lsx_diag_chain_head_f64(lsx_handle_t h, int fused, int jb, const double *dT, int ldt, double *dTinv, int ncols,
                             double *dA, int lda, int row0, const int32_t *d_moves) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dT && dTinv && jb >= 1 && jb <= 128);
     if (!fused) return launch_trtri<double>(h, 1, jb, dT, ldt, dTinv);
     LSX_ARG(dA && d_moves);
@@ -1283,6 +1389,7 @@ int lsx_diag_chain_head_f64(lsx_handle_t h, int fused, int jb, const double *dT,
 
 // ---- measurement
 int lsx_prof_enable(lsx_handle_t h, int on) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     // 0 = off, 1 = every bucket, otherwise a bit mask (1 << LSX_PROF_*) shifted left by one:
     // e.g. 2 << LSX_PROF_GEMM brackets only the trailing-update launches
@@ -1304,6 +1411,7 @@ static int prof_drain(lsx_handle_t h) {
 }
 
 int lsx_prof_reset(lsx_handle_t h) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h);
     LSX_TRY(prof_drain(h));
     for (int b = 0; b < LSX_PROF_NBUCKETS; ++b) {
@@ -1314,6 +1422,7 @@ int lsx_prof_reset(lsx_handle_t h) {
 
 int lsx_prof_read(lsx_handle_t h, int bucket, double *ms, long long *launches, double *flops,
                   double *bytes) {
+    LSX_DEVICE_GUARD(h);
     LSX_ARG(h && bucket >= 0 && bucket < LSX_PROF_NBUCKETS);
     LSX_TRY(prof_drain(h));
     if (ms) *ms = h->prof.ms[bucket];

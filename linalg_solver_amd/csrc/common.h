@@ -109,6 +109,10 @@ struct lsx_handle_s {
     bool moves_valid = false;   // set by the last panel launch when `moves` describes its interchanges
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
+    // device status words (never cleared by kernels): [0] panel exchange time-outs when the caller gave no info
+    // word, [1] few-RHS solve time-outs, [2] the internal info word of a factorisation called without one
+    int *dev_status = nullptr;
+    int spin_limit = 1 << 20;   // polls before a cooperative solve gives up (option trsv_spin_limit: tests)
     lsx::Prof prof;
 };
 

@@ -190,7 +190,8 @@ __device__ __forceinline__ float quad_sum(float v) {
 template <typename T, int NR, bool LOWER>
 __global__ __launch_bounds__(256) void trsv_coop_kernel(int n, const T *__restrict__ LU, int lda,
                                                         const T *__restrict__ inv64, const T *__restrict__ Bin,
-                                                        int ldb, T *__restrict__ X, XGran *xb, int *status) {
+                                                        int ldb, T *__restrict__ X, XGran *xb, int *status,
+                                                        int spin_limit) {
     constexpr int LSD = CB + 2;            // LDS row stride of a staged factor block
     constexpr int NF = (CB * CB + 191) / 192;   // factor entries per loader thread (waves 1-3)
     __shared__ __attribute__((aligned(16))) T Ls[3][CB][LSD];   // factor blocks of steps i, i+1, i+2
@@ -203,9 +204,12 @@ __global__ __launch_bounds__(256) void trsv_coop_kernel(int n, const T *__restri
     __shared__ T bown[4 * XG];
     auto XI = [](const int r, const int q) __attribute__((always_inline)) { return (r >> 4) * XG + (r & 15) * NR + q; };
     __shared__ int s_fail;
-    const int tid = threadIdx.x, w = blockIdx.x;
-    const int r0 = w * CB;
     const int nblk = (n + CB - 1) / CB;
+    // The upper solve runs from the last block row upwards: workgroups are numbered so that every dependency
+    // points to a LOWER blockIdx, i.e. to a workgroup the dispatcher placed earlier -- a workgroup that is not
+    // resident yet can then never be waited for by one that holds a CU.
+    const int tid = threadIdx.x, w = LOWER ? (int)blockIdx.x : nblk - 1 - (int)blockIdx.x;
+    const int r0 = w * CB;
     const int row_l = tid >> 2, part = tid & 3;   // 4 threads per row, 16 columns of the block each
     const int row = r0 + row_l;
     __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(xb, 0, nblk * CB * NR * (int)sizeof(XGran), 0x00020000);
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) void trsv_coop_kernel(int n, const T *__restri
                         }
                         break;
                     }
-                    if (s_fail || ++spins > (1 << 20)) { s_fail = 1; break; }
+                    if (s_fail || ++spins > spin_limit) { s_fail = 1; break; }
                 }
             }
 #pragma unroll
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(256) void trsv_coop_kernel(int n, const T *__restri
             }
         }
     }
+    // a time-out (x_k substituted by zero above) must not pass for a result: the host entry points read this word
     if (s_fail && tid == 0) atomicExch(status, 1);
 }
 
@@ -346,14 +351,15 @@ static int trsv_coop_run(lsx_handle_t h, int n, const T *LU, int lda, T *B, int 
         // one launch per direction; exchange area (zeroed) + status word in the scratch
         const size_t xbytes = (size_t)wgs * CB * NR * sizeof(XGran);
         if (256 + 2 * xbytes > h->scratch_bytes) { set_error("trsv: scratch too small"); return LSX_ERR_INTERNAL; }
-        int *status = (int *)h->scratch;
+        int *status = h->dev_status + 1;   // persistent word: read (and cleared) by the host entry points / lsx_check_status
+        const int spin_limit = h->spin_limit;
         XGran *xb0 = (XGran *)((char *)h->scratch + 256), *xb1 = (XGran *)((char *)h->scratch + 256 + xbytes);
         LSX_HIP(hipMemsetAsync(h->scratch, 0, 256 + 2 * xbytes, h->stream));
         hipLaunchKernelGGL((trsv_coop_kernel<T, NR, true>), dim3(wgs), dim3(256), 0, h->stream, n, LU, lda, inv64L,
-                           (const T *)B, ldb, X, xb0, status);
+                           (const T *)B, ldb, X, xb0, status, spin_limit);
         LSX_TRY(launch_copy2d<T>(h, n, NR, X, NR, B, ldb));  // y is the right-hand side of U x = y
         hipLaunchKernelGGL((trsv_coop_kernel<T, NR, false>), dim3(wgs), dim3(256), 0, h->stream, n, LU, lda, inv64U,
-                           (const T *)B, ldb, X, xb1, status);
+                           (const T *)B, ldb, X, xb1, status, spin_limit);
         LSX_HIP(hipGetLastError());
         return LSX_OK;
     }

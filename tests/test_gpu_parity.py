@@ -910,3 +910,45 @@ def test_full_size_fp32_solution_within_1e4_of_the_fp64_solution(dev):
     # three sweeps gain about two digits each here (cond * eps32 ~ 1e-2): 9e-3 -> 6e-9 measured
     assert err < 1e-6 and err32 < 1e-6 < TOL32 and err0 > err32
     assert st[0] / st[1] < 1e-5
+
+
+def test_cooperative_solve_timeout_is_an_error_not_a_result(la):
+    """a time-out of the few-RHS cooperative solve (x_k replaced by zero inside the kernel) must come
+    back as LSX_ERR_INTERNAL from the host entry points, never as a solution.  Forced here by a spin limit of 0
+    (the first unanswered poll gives up); the handle is usable again afterwards."""
+    from linalg_solver_amd import _native, dense, gen
+
+    h = la.default_handle()
+    n = 3000
+    A, b = gen.system(gen.U11, 31, n)
+    LU, ipiv, info = dense.lu_factor(A)
+    assert info == 0
+    try:
+        h.set_option("trsv_spin_limit", 0)
+        with pytest.raises(_native.LsxError):
+            dense.lu_solve(LU, ipiv, b)
+    finally:
+        h.set_option("trsv_spin_limit", 1 << 20)
+    h.check_status()   # the word was cleared with the error
+    x = dense.lu_solve(LU, ipiv, b)
+    assert np.max(np.abs(A @ x - b)) / (np.max(np.abs(A)) * np.max(np.abs(x)) * n) < 1e-14
+
+
+def test_getrf_dev_without_an_info_word_still_records_failures(dev):
+    """*_dev entry points accept d_info = NULL; the factorisation then keeps an internal word that
+    lsx_check_status reads.  (Here: nothing failed, the check passes and the factors are right.)"""
+    import torch
+
+    from linalg_solver_amd import _native, gen
+
+    n = 700
+    A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    dev.fill_(A0, gen.U11, 12)
+    LU = A0.clone()
+    ipiv = torch.empty(n, dtype=torch.int32, device="cuda")
+    _native.check(dev.lib.lsx_getrf_f64_dev(dev.h.ptr, n, LU.data_ptr(), n, ipiv.data_ptr(), None), "getrf_dev")
+    dev.h.check_status()
+    LU2 = A0.clone()
+    ipiv2, info2 = dev.getrf_(LU2)
+    torch.cuda.synchronize()
+    assert int(info2.item()) == 0 and torch.equal(LU, LU2) and torch.equal(ipiv, ipiv2)
