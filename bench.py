@@ -38,7 +38,8 @@ def lu_flops(n: int) -> float:
 
 def cpu_baseline(sample_n: int):
     """The oracle's C restatement of the reference's row_reduce (1 core: the reference is
-    sequential by construction) on a bounded sample of the same generator."""
+    sequential by construction) on a bounded sample of the same generator, and LAPACK's
+    dgetrf on all host cores of the box beside it (warmed up: the first call pays thread start-up)."""
     import numpy as np
 
     from linalg_solver_amd import gen
@@ -57,13 +58,24 @@ def cpu_baseline(sample_n: int):
     try:
         import scipy.linalg as sl
 
+        cores = len(os.sched_getaffinity(0))
+        pools = None
+        try:
+            from threadpoolctl import threadpool_info
+
+            pools = [{k: p.get(k) for k in ("internal_api", "num_threads", "version")} for p in threadpool_info()]
+        except Exception:
+            pass
         n2 = 4096
         A2 = gen.fill(gen.U11, 1, n2, n2)
-        t0 = time.perf_counter()
-        sl.lu_factor(A2, check_finite=False)
-        dt2 = time.perf_counter() - t0
-        out["lapack_dgetrf"] = {"value": lu_flops(n2) / dt2 / 1e9, "unit": "GFLOP/s", "n": n2,
-                                "cores": len(os.sched_getaffinity(0))}
+        sl.lu_factor(A2[:1024, :1024].copy(), check_finite=False)   # warm-up: thread pool, code paths
+        best = 1e30
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sl.lu_factor(A2, check_finite=False)
+            best = min(best, time.perf_counter() - t0)
+        out["lapack_dgetrf"] = {"value": lu_flops(n2) / best / 1e9, "unit": "GFLOP/s", "n": n2, "cores": cores,
+                                "threadpools": pools, "note": "scipy.linalg.lu_factor, best of 3 after a warm-up call"}
     except Exception as e:  # scipy is optional plumbing here
         out["lapack_dgetrf"] = {"error": str(e)}
     return out
@@ -72,13 +84,13 @@ def cpu_baseline(sample_n: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=0, help="matrix order (default: 8192 per-GPU-flop-equivalent)")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--nb", type=int, default=0)
     ap.add_argument("--panel", type=int, default=-1)
-    ap.add_argument("--cpu-sample", type=int, default=3072)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip solve-latency / 4096 side measurements")
     args = ap.parse_args()
@@ -152,18 +164,33 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    # live HIP events over the timed region, on the launch stream, for the dominant kernel only
-    # (bracketing every launch of every phase costs ~7 % of the step; the full per-phase
-    # breakdown comes from one extra, untimed step below)
+    # live HIP events over the timed region, on the launch stream, for the TIME-DOMINANT kernel only: the panel
+    # factorisation (one launch per 128 columns, on the look-ahead driver's side stream).  Bracketing every
+    # launch of every phase costs ~7 % of the step; the trailing update is measured by an extra, untimed pass of
+    # the same driver below (`roofline_update`), the full per-phase breakdown by a sequential step.
     dev.h.prof_reset()
-    dev.h.prof_enable(buckets=("gemm",))   # not "gemm_skinny": those launches sit on the panel-to-panel chain
+    PANEL_SAMPLE = 7 if world == 1 else 1   # every 7th panel launch (7 and the 64 panels of a step are coprime:
+    dev.h.set_option("prof_sample", PANEL_SAMPLE)   # over the steps every panel height is sampled): the events sit
+    dev.h.prof_enable(buckets=("panel",))           # on the panel-to-panel chain and would cost 4 % if all were bracketed
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
     dev.h.prof_enable(False)
+    dev.h.set_option("prof_sample", 1)
     prof = dev.h.prof_read()
+    # the trailing update under the SAME driver (look-ahead: it runs beside the next panel), untimed extra pass
+    prof_upd = None
+    if world == 1:
+        dev.h.prof_reset()
+        dev.fill_(mats[0], gen.U11, 1)
+        barrier()
+        dev.h.prof_enable(buckets=("gemm",))
+        step(0)
+        barrier()
+        dev.h.prof_enable(False)
+        prof_upd = dev.h.prof_read()["gemm"]
     # Per-phase breakdown: one more, untimed step with every phase bracketed by events.  On one GPU it
     # runs the SEQUENTIAL driver (lookahead=0): under look-ahead the panel and the update overlap and
     # their brackets no longer add up to the step.  The same step gives the dominant kernel's duration
@@ -213,9 +240,29 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = lu_flops(n) * args.steps / dt / 1e9
-    g = prof["gemm"]
+    pl = prof["panel"]                          # live, timed region
+    g = prof_upd if prof_upd else prof["gemm"]
     gemm_tflops = (g["flops"] / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else 0.0
     p = phases["panel"]
+    panel_gbs = (pl["bytes"] / (pl["ms"] * 1e-3) / 1e9) if pl["ms"] > 0 else 0.0
+    panels_per_step = (n + nb - 1) // nb
+    panel_ms_per_step = pl["ms"] / max(pl["launches"], 1) * panels_per_step   # sampled launches -> all of a step's
+    pmc_panel = None
+    try:
+        import glob
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_panel.json")))[-1]
+        pmc_panel = json.load(open(f))
+        pmc_panel["source"] = os.path.relpath(f, ROOT)
+    except Exception:
+        pass
+    hops = None
+    if world == 1 and not args.no_extras:
+        try:   # the exchange under the panel's column chain, measured in this run
+            hops = {"xcd_scope_one_way_us": dev.h.xchg_probe(2, 32, 8, False, 2000)[0] / 2,
+                    "device_scope_one_way_us": dev.h.xchg_probe(2, 32, 1, True, 2000)[0] / 2,
+                    "xcd_scope_allgather_plus_row_us": dev.h.xchg_probe(1, 32, 8, False, 2000)[0]}
+        except Exception as e:  # noqa: BLE001
+            hops = {"error": str(e)}
     out = {
         "metric": "fp64_lu_gflops" if args.dtype == "f64" else "fp32_lu_gflops",
         "value": value, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -223,27 +270,43 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{n}x{n} {args.dtype} LU with partial pivoting (getrf), u11 generator, resident in HBM",
                    "n": n, "nb": nb, "panel_mode": dev.h.get_option("panel"),
-                   "lookahead": (look_default if n >= (7168 if args.dtype == "f64" else 10240) else 0) if world == 1 else "depth-1, sharded driver",
+                   "lookahead": look_default if world == 1 else "depth-1, sharded driver",
                    "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic columns x{world}, panel broadcast (RCCL)"},
-        "roofline": {"bound": "mfma", "kernel": "gemm_sub_kernel<T,.,true,128> (trailing update C -= L21*U12, 128x128 tiles)",
-                     "achieved": gemm_tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-                     "frac": gemm_tflops / PEAK[args.dtype],
-                     "traffic": (g["bytes"] / max(g["launches"], 1) * pmc_ratio) if pmc_ratio else None,
-                     "traffic_note": (f"avg HBM bytes per launch = algorithmic x {pmc_ratio:.3f}, ratio from PMC pass "
-                                      f"{pmc_src}") if pmc_ratio else "no PMC pass available",
-                     "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
-                     "mfma_sustained_tflops_microbench": sustained,
-                     "launches": g["launches"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
-                     "algorithmic_bytes": g["bytes"],
-                     "note": "launches of the 64-row-tile form of the same update (the next panel's column block on "
-                             "the look-ahead chain) are a separate bucket, `gemm_skinny`, and not in `achieved`",
-                     "algorithmic_gbs": (g["bytes"] / (g["ms"] * 1e-3) / 1e9) if g["ms"] > 0 else 0.0},
+        # the time-dominant kernel of the step: the panel factorisation.  SURVEY 8d prices it against HBM
+        # (algorithmic bytes = each panel read + written once = 2 * sizeof(T) * m * nb per launch); what actually bounds
+        # it is one cross-CU pivot exchange per column -- latency, stated beside the fraction.
+        "roofline": {"bound": "hbm",
+                     "kernel": "panel_x_kernel (panel factorisation, XCD-scope pivot exchange; panels taller than one "
+                               "XCD holds: panel_pipe_kernel)" if dev.h.get_option("panel") == 4 else "panel_pipe_kernel",
+                     "achieved": panel_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": panel_gbs / HBM_PEAK_GBS,
+                     "traffic": (pmc_panel or {}).get("hbm_bytes_per_launch"),
+                     "traffic_note": (f"PMC pass {pmc_panel['source']}: {pmc_panel.get('note', '')}" if pmc_panel
+                                      else "no PMC pass available"),
+                     "launches": pl["launches"], "avg_launch_ms": pl["ms"] / max(pl["launches"], 1),
+                     "algorithmic_bytes_per_launch": pl["bytes"] / max(pl["launches"], 1),
+                     "algorithmic_bytes": pl["bytes"],
+                     "share_of_step": panel_ms_per_step / ms_per_step if ms_per_step > 0 else None,
+                     "us_per_column": (pl["ms"] * 1e3 / max(pl["launches"], 1) / nb) if world == 1 else None,
+                     "sampling": f"every {PANEL_SAMPLE}th launch bracketed by HIP events on its launch stream",
+                     "latency_bound": {"note": "true partial pivoting needs one cross-CU exchange per column; the kernel's "
+                                               "floor is columns x (one-way hop + the owner wave's instruction stream), "
+                                               "not bytes / bandwidth", "hops": hops},
+                     "whole_lu_frac_of_mfma_peak": value / 1e3 / PEAK[args.dtype]},
+        "roofline_update": {"bound": "mfma", "kernel": "gemm_sub_queue_kernel / gemm_sub_kernel<T,.,true,128> (trailing update "
+                                                       "C -= L21*U12, 128x128 tiles)",
+                            "achieved": gemm_tflops, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                            "frac": gemm_tflops / PEAK[args.dtype],
+                            "cus": "7 of 8 XCDs while a panel runs on the eighth (look-ahead driver)" if dev.h.get_option("panel") == 4 else "all",
+                            "frac_of_the_cus_it_runs_on": gemm_tflops / (PEAK[args.dtype] * 7 / 8) if dev.h.get_option("panel") == 4 else None,
+                            "traffic": (g["bytes"] / max(g["launches"], 1) * pmc_ratio) if pmc_ratio else None,
+                            "traffic_note": (f"avg HBM bytes per launch = algorithmic x {pmc_ratio:.3f}, ratio from PMC pass "
+                                             f"{pmc_src}") if pmc_ratio else "no PMC pass available",
+                            "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
+                            "mfma_sustained_tflops_microbench": sustained,
+                            "launches": g["launches"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
+                            "note": "extra untimed pass of the same look-ahead driver with only these launches bracketed"},
         "phases_ms_per_step": {k: v["ms"] for k, v in phases.items()},
         "phases_note": "one extra untimed step of the sequential driver (lookahead=0) with every phase bracketed by events",
-        "panel_roofline": {"bound": "hbm", "achieved": (p["bytes"] / (p["ms"] * 1e-3) / 1e9) if p["ms"] > 0 else 0.0,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ((p["bytes"] / (p["ms"] * 1e-3) / 1e9) / HBM_PEAK_GBS) if p["ms"] > 0 else 0.0,
-                           "algorithmic_bytes_per_step": p["bytes"]},
     }
 
     gs = phases["gemm"]
@@ -252,9 +315,8 @@ def main():
         out["roofline_sequential"] = {"achieved": seq_tf, "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                                       "frac": seq_tf / PEAK[args.dtype], "launches": gs["launches"],
                                       "avg_launch_ms": gs["ms"] / max(gs["launches"], 1),
-                                      "note": "the same kernel with the chip to itself (lookahead=0 step); in the timed "
-                                              "region it shares the CUs with the next panel's workgroups"}
-    if world == 1 and not args.no_extras and n >= 7168:
+                                      "note": "the update kernel with the chip to itself (lookahead=0 step)"}
+    if world == 1 and not args.no_extras and n >= 3072:
         # the sequential driver end to end, for comparison (bit-identical factors)
         dev.h.set_option("lookahead", 0)
         ts = []
@@ -325,6 +387,43 @@ def main():
             out["config3_inverse"] = {"getri_ms": t_inv * 1e3, "lu_plus_inverse_ms": t_inv * 1e3 + ms_per_step,
                                       "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9,
                                       "max_abs_A_inv_minus_I": ident_err}
+    if world == 1 and not args.no_extras and args.dtype == "f64":
+        # config #5: 8192 x 8192 in fp32 -- factorisation time, and the SOLUTION against the fp64 result
+        # ("tolerance 1e-4"): fp32 factors + fp64 residuals (lsx_gesv_f32_refined_dev), 4 right-hand sides
+        n5 = 8192
+        A32 = torch.empty(n5, n5, dtype=torch.float32, device="cuda")
+        B32 = torch.empty(n5, 4, dtype=torch.float32, device="cuda")
+        dev.fill_(A32, gen.U11, 5)
+        dev.fill_(B32, gen.U11, 6)
+        LU5 = A32.clone()
+        ip5 = torch.empty(n5, dtype=torch.int32, device="cuda")
+        ts = []
+        for r in range(3):
+            LU5.copy_(A32)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dev.getrf_(LU5, ip5, info)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        X64, X32, _, _, info5, st5 = dev.gesv_refined(A32, B32, sweeps=3)
+        torch.cuda.synchronize()
+        t_ref = time.perf_counter() - t0
+        A64 = A32.double()
+        Xd = B32.double().clone()
+        ip64, info64 = dev.getrf_(A64)
+        dev.getrs_(A64, ip64, Xd)
+        X0 = B32.clone()
+        dev.getrs_(LU5, ip5, X0)
+        torch.cuda.synchronize()
+        sc = float(Xd.abs().max())
+        out["config5_fp32"] = {"lu_ms": min(ts[1:]) * 1e3, "lu_gflops": lu_flops(n5) / min(ts[1:]) / 1e9,
+                               "refined_solve_4rhs_ms_incl_lu": t_ref * 1e3, "sweeps": 3,
+                               "forward_error_vs_fp64_refined": float((X32.double() - Xd).abs().max()) / sc,
+                               "forward_error_vs_fp64_unrefined": float((X0.double() - Xd).abs().max()) / sc,
+                               "tolerance": 1e-4, "info": int(info5.item())}
+        del A64, Xd, X0, LU5, A32
     if world == 1 and not args.no_extras and args.dtype == "f64":
         # config #1 (the reference's own CPU-runnable case): 64 x 64 ints in [-5,5] as floats + rhs through
         # the Matrix surface -- fast path, traced path (reference-order arithmetic + step list) and traced

@@ -76,6 +76,7 @@ static int ensure_scratch(lsx_handle_t h, size_t bytes) {
 ProfScope::ProfScope(lsx_handle_t h_, int bucket, double flops, double bytes) : h(h_), st(h_->stream) {
     Prof &p = h->prof;
     if (!((p.mask >> bucket) & 1u)) return;
+    if (p.sample > 1 && (p.seen[bucket]++ % p.sample) != 0) return;
     ProfEvent ev;
     ev.bucket = bucket;
     for (hipEvent_t *e : {&ev.a, &ev.b}) {
@@ -865,6 +866,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_nt")) {
         LSX_ARG(value == 0 || value == 256 || value == 512 || value == 1024);
         h->panel_nt = value;
+    } else if (!strcmp(key, "prof_sample")) {   // bracket every value-th launch of a profiled bucket
+        LSX_ARG(value >= 1);
+        h->prof.sample = value;
     } else if (!strcmp(key, "trsv_spin_limit")) {   // tests: 0 makes the first unanswered poll a time-out
         LSX_ARG(value >= 0);
         h->spin_limit = value;
@@ -1415,7 +1419,7 @@ int lsx_prof_reset(lsx_handle_t h) {
     LSX_ARG(h);
     LSX_TRY(prof_drain(h));
     for (int b = 0; b < LSX_PROF_NBUCKETS; ++b) {
-        h->prof.ms[b] = 0; h->prof.launches[b] = 0; h->prof.flops[b] = 0; h->prof.bytes[b] = 0;
+        h->prof.ms[b] = 0; h->prof.launches[b] = 0; h->prof.flops[b] = 0; h->prof.bytes[b] = 0; h->prof.seen[b] = 0;
     }
     return LSX_OK;
 }

@@ -43,6 +43,8 @@ struct ProfEvent {
 
 struct Prof {
     unsigned mask = 0;  // bit b set: launches of bucket b are bracketed by events
+    int sample = 1;     // bracket every sample-th launch of a bucket only (events on the look-ahead chain cost time)
+    long long seen[LSX_PROF_NBUCKETS] = {0};
     std::vector<ProfEvent> pending;
     std::vector<hipEvent_t> pool;
     double ms[LSX_PROF_NBUCKETS] = {0};
