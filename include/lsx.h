@@ -252,6 +252,9 @@ int lsx_diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu,
  * 0 = plain stores (XCD scope: only meaningful when xcc_ids come back all equal).  xcc_ids[G] may be NULL. */
 int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_through, int epochs,
                         double *us_per_epoch, int *xcc_ids, int *nfail);
+/* Diagnostics (residency tests): hold `wgs` (1..32) CUs of XCD `xcc` for `ms` milliseconds with a filler kernel on
+ * a stream of its own; returns at once. */
+int lsx_diag_occupy(lsx_handle_t h, int xcc, int wgs, int ms);
 /* Diagnostics: launch nblocks workgroups on a stream created with the given CU mask (nwords = 0: the handle's
  * stream) and report where each landed: out[2 b] = XCC id, out[2 b + 1] = HW_ID register.  Synchronous. */
 int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out);

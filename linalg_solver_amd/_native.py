@@ -11,7 +11,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblsx.so")
+LIB_PATH = os.environ.get("LSX_LIB_OVERRIDE") or os.path.join(_HERE, "liblsx.so")   # override: timing experiments (tools/)
 
 PROF_BUCKETS = {"panel": 0, "laswp": 1, "trsm": 2, "gemm": 3, "other": 4, "gemm_skinny": 5}
 FILL_INT5, FILL_U11 = 0, 1
@@ -80,6 +80,7 @@ _SIGS = {
     "lsx_diag_xchg_probe": [_vp, _i, _i, _i, _i, _i, _dp, _ip, _ip],
     "lsx_diag_chain_head_f32": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "lsx_diag_chain_head_f64": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
+    "lsx_diag_occupy": [_vp, _i, _i, _i],
     "lsx_diag_cu_mask_probe": [_vp, C.POINTER(C.c_uint32), _i, _i, C.POINTER(C.c_uint32)],
     "lsx_prof_enable": [_vp, _i],
     "lsx_prof_reset": [_vp],
@@ -198,6 +199,10 @@ class Handle:
         check(self.lib.lsx_diag_xchg_probe(self._h, mode, G, stride, 1 if write_through else 0, epochs,
                                            C.byref(us), ids, C.byref(nf)), "diag_xchg_probe")
         return us.value, list(ids), nf.value
+
+    def occupy(self, xcc: int, wgs: int, ms: int):
+        """Hold `wgs` CUs of XCD `xcc` for `ms` milliseconds (asynchronous filler; residency tests)."""
+        check(self.lib.lsx_diag_occupy(self._h, xcc, wgs, ms), "diag_occupy")
 
     def cu_mask_probe(self, mask_bits, nblocks: int = 2048):
         """Where the workgroups of a CU-masked stream land: list of (xcc, hw_id) per block; mask_bits = iterable

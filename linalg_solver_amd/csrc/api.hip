@@ -615,6 +615,36 @@ static int d2h(lsx_handle_t h, int m, int n, const T *src, int lds, T *dst, int 
 
 static int ld_for(int n) { return (n + 15) & ~15; }  // device leading dimension: 128-B rows (fp64)
 
+// Host-buffer entry points: upload, factor, read the info word -- and when the cooperative panel's exchange timed out
+// (its workgroups were not all resident at once: something else held the CUs for longer than the bounded spin), upload
+// again and factor with panel mode 0 (two plain launches per column, no workgroup waits for another) instead of
+// failing.  hinfo < 0 on return only if that also failed.  Synchronises the handle's stream.
+template <typename T>
+static int factor_from_host(lsx_handle_t h, int n, const T *A, int lda, T *dA, int ld, int32_t *dp, int *dinfo,
+                            int *hinfo) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
+        int rc;
+        if (attempt == 0) {
+            rc = getrf_dev<T>(h, n, dA, ld, dp, dinfo);
+        } else {
+            const int mode = h->panel_mode, look = h->lookahead;
+            h->panel_mode = 0;
+            h->lookahead = 0;
+            rc = getrf_dev<T>(h, n, dA, ld, dp, dinfo);
+            h->panel_mode = mode;
+            h->lookahead = look;
+            h->panel_fallbacks += 1;
+        }
+        LSX_TRY(rc);
+        LSX_HIP(hipMemcpyAsync(hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        LSX_HIP(hipStreamSynchronize(h->stream));
+        if (*hinfo >= 0) return LSX_OK;
+    }
+    set_error("panel exchange timed out on the device, and so did the per-column fallback");
+    return LSX_ERR_INTERNAL;
+}
+
 template <typename T>
 static int getrf_host(lsx_handle_t h, int n, T *A, int lda, int32_t *ipiv, int *info) {
     LSX_ARG(h && n >= 0 && lda >= n && (n == 0 || (A && ipiv)));
@@ -626,18 +656,12 @@ static int getrf_host(lsx_handle_t h, int n, T *A, int lda, int32_t *ipiv, int *
     T *dA = c.take<T>((size_t)n * ld);
     int32_t *dp = c.take<int32_t>(n);
     int *dinfo = c.take<int>(1);
-    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
-    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    int hinfo = 0;
+    LSX_TRY(factor_from_host<T>(h, n, A, lda, dA, ld, dp, dinfo, &hinfo));
     LSX_TRY(d2h<T>(h, n, n, dA, ld, A, lda));
     LSX_HIP(hipMemcpyAsync(ipiv, dp, sizeof(int32_t) * n, hipMemcpyDeviceToHost, h->stream));
-    int hinfo = 0;
-    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
-    if (hinfo < 0) {
-        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
-        return LSX_ERR_INTERNAL;
-    }
     return LSX_OK;
 }
 
@@ -681,22 +705,17 @@ static int gesv_host(lsx_handle_t h, int n, int nrhs, const T *A, int lda, T *B,
     int32_t *dp = c.take<int32_t>(n);
     int *dinfo = c.take<int>(1);
     double *dprobe = c.take<double>(2);
-    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
     if (nrhs > 0) LSX_TRY(h2d<T>(h, n, nrhs, B, ldb, dB, ldx));
+    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
     LSX_TRY(launch_amax<T>(h, n, n, dA, ld, dprobe));
-    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
-    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
     int hinfo = 0;
+    LSX_TRY(factor_from_host<T>(h, n, A, lda, dA, ld, dp, dinfo, &hinfo));
+    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
     double probe[2] = {0, 0};
-    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipMemcpyAsync(probe, dprobe, sizeof(probe), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
     if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
-    if (hinfo < 0) {
-        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
-        return LSX_ERR_INTERNAL;
-    }
     if (hinfo != 0 || nrhs == 0) return LSX_OK;  // singular: B is left untouched
     LSX_TRY(getrs_dev<T>(h, n, nrhs, dA, ld, dp, dB, ldx));
     LSX_TRY(check_dev_status(h));
@@ -869,6 +888,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "prof_sample")) {   // bracket every value-th launch of a profiled bucket
         LSX_ARG(value >= 1);
         h->prof.sample = value;
+    } else if (!strcmp(key, "panel_spin_limit")) {   // tests: a short limit turns a held-up panel into a time-out;
+        LSX_ARG(value != 0);                           // negative: |value| and one participant arrives late
+        h->panel_spin_limit = value;
     } else if (!strcmp(key, "trsv_spin_limit")) {   // tests: 0 makes the first unanswered poll a time-out
         LSX_ARG(value >= 0);
         h->spin_limit = value;
@@ -904,6 +926,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "trsv")) *value = h->trsv_mode;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
+    else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
     return LSX_OK;
@@ -960,19 +983,14 @@ static int getri_host(lsx_handle_t h, int n, const T *A, int lda, T *Ainv, int l
     double *dprobe = c.take<double>(2);
     LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
     LSX_TRY(launch_amax<T>(h, n, n, dA, ld, dprobe));
-    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
-    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
     int hinfo = 0;
+    LSX_TRY(factor_from_host<T>(h, n, A, lda, dA, ld, dp, dinfo, &hinfo));
+    LSX_TRY(launch_diag_minabs<T>(h, n, dA, ld, dprobe));
     double probe[2] = {0, 0};
-    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipMemcpyAsync(probe, dprobe, sizeof(probe), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
     if (info) *info = hinfo;
     if (pivot_ratio) *pivot_ratio = probe[0] > 0 ? probe[1] / probe[0] : 0.0;
-    if (hinfo < 0) {
-        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
-        return LSX_ERR_INTERNAL;
-    }
     if (hinfo != 0) return LSX_OK;  // exactly singular: caller reports NoSolution (linalg.py:737)
     LSX_TRY(getri_dev<T>(h, n, dA, ld, dp, dI, ld));
     LSX_TRY(d2h<T>(h, n, n, dI, ld, Ainv, ldi));
@@ -992,18 +1010,12 @@ static int det_host(lsx_handle_t h, int n, const T *A, int lda, double *sign, do
     int32_t *dp = c.take<int32_t>(n);
     int *dinfo = c.take<int>(1);
     double *dout = c.take<double>(3);
-    LSX_TRY(h2d<T>(h, n, n, A, lda, dA, ld));
-    LSX_TRY(getrf_dev<T>(h, n, dA, ld, dp, dinfo));
+    int hinfo = 0;   // a determinant of garbage factors must not be returned as a value: the status is read first
+    LSX_TRY(factor_from_host<T>(h, n, A, lda, dA, ld, dp, dinfo, &hinfo));
     LSX_TRY(launch_det<T>(h, n, dA, ld, dp, dout));
     double out[3];
-    int hinfo = 0;
     LSX_HIP(hipMemcpyAsync(out, dout, sizeof(out), hipMemcpyDeviceToHost, h->stream));
-    LSX_HIP(hipMemcpyAsync(&hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     LSX_HIP(hipStreamSynchronize(h->stream));
-    if (hinfo < 0) {   // a determinant of garbage factors must not be returned as a value
-        set_error("panel exchange timed out on the device (workgroups not co-resident?)");
-        return LSX_ERR_INTERNAL;
-    }
     *sign = out[0]; *mant = out[1]; *exp2 = (int64_t)out[2];
     return LSX_OK;
 }
@@ -1364,6 +1376,12 @@ int lsx_diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int write_t
     LSX_ARG(h && us_per_epoch && nfail && G >= 2 && G <= 64 && (stride == 1 || stride == 8) && epochs >= 1);
     LSX_ARG(mode >= 0 && mode <= 2 && (G - 1) * stride + 1 <= 8 * h->num_cu);
     return diag_xchg_probe(h, mode, G, stride, write_through, epochs, us_per_epoch, xcc_ids, nfail);
+}
+
+int lsx_diag_occupy(lsx_handle_t h, int xcc, int wgs, int ms) {
+    LSX_DEVICE_GUARD(h);
+    LSX_ARG(h && xcc >= 0 && xcc < 8 && wgs >= 1 && wgs <= 32 && ms >= 1 && ms <= 10000);
+    return diag_occupy(h, xcc, wgs, ms);
 }
 
 int lsx_diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, uint32_t *out) {

@@ -114,6 +114,8 @@ struct lsx_handle_s {
     // device status words (never cleared by kernels): [0] panel exchange time-outs when the caller gave no info
     // word, [1] few-RHS solve time-outs, [2] the internal info word of a factorisation called without one
     int *dev_status = nullptr;
+    int panel_fallbacks = 0;    // host-buffer factorisations redone with panel mode 0 after an exchange time-out
+    int panel_spin_limit = 1 << 20;   // polls before the XCD-scope panel gives up on a neighbour (option: tests)
     int spin_limit = 1 << 20;   // polls before a cooperative solve gives up (option trsv_spin_limit: tests)
     lsx::Prof prof;
 };
@@ -233,6 +235,7 @@ int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B
                      T *inv64U, T *inv128L, T *inv128U);
 int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz);
 int diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, unsigned *out_host);
+int diag_occupy(lsx_handle_t h, int xcc, int wgs, int ms);
 int diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int wt, int epochs, double *us_per_epoch,
                     int *xcc_ids, int *nfail);
 template <typename T>

@@ -275,3 +275,31 @@ int diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, i
 }
 
 }  // namespace lsx
+
+// ---------------------------------------------------------------------------------------------
+// A filler that holds `wgs` CUs of one XCD for `ms` milliseconds (one 1024-thread workgroup with 100 KB of LDS per
+// CU; workgroups dealt to other XCDs leave at once).  Asynchronous, on the handle's side stream.  For the residency
+// tests: the cooperative panel's workgroups then cannot all be resident and its bounded spins must end in the
+// per-column fallback, not in a hang or in wrong factors (tests/test_gpu_parity.py).
+namespace lsx {
+
+__global__ __launch_bounds__(1024) void occupy_kernel(int xcc_want, unsigned long long ticks) {
+    __shared__ char pad[100 * 1024];
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    if ((int)xcc != xcc_want) return;
+    if (threadIdx.x == 0) pad[0] = 1;   // keep the allocation
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+    if (threadIdx.x == 2000) pad[1] = pad[0];
+}
+
+int diag_occupy(lsx_handle_t h, int xcc, int wgs, int ms) {
+    // on the handle's look-ahead side stream: a stream created here may be mapped to the hardware queue of the
+    // handle's main stream (the runtime multiplexes streams over a few queues), and kernels of one queue run in order
+    hipLaunchKernelGGL(occupy_kernel, dim3(8 * wgs), dim3(1024), 0, h->side_stream, xcc, (unsigned long long)ms * 100000ull);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+}  // namespace lsx

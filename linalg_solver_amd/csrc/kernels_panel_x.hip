@@ -65,7 +65,7 @@ template <typename T, int RT, bool DBG, bool XCD>
 __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, int jb, T *__restrict__ P, int ldp,
                                              int row0, int col0, int32_t *__restrict__ ipiv,
                                              int *__restrict__ info, char *rec, XGran *far, int *status,
-                                             unsigned long long *dbg, int2 *__restrict__ moves) {
+                                             unsigned long long *dbg, int2 *__restrict__ moves, const int spin_limit) {
     constexpr int NT = PX_NT, WC = PX_WC;
     constexpr int NW = NT / 64;   // waves
     constexpr int RB = 64 * RT;   // panel rows per workgroup
@@ -95,22 +95,14 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         tlast = tn_;                                                          \
     }
 
-    auto raw_desc = [](const void *p, unsigned bytes) __attribute__((always_inline)) {
-        const unsigned long long b = (unsigned long long)p;
-        u4 d;
-        d.x = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-        d.y = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) & 0xffffu;
-        d.z = (unsigned)__builtin_amdgcn_readfirstlane((int)bytes);
-        d.w = 0x00020000u;
-        return d;
-    };
-    const u4 d_rec = raw_desc(rec, 2u * G * PX_REC);
+    // one descriptor per exchange region, shared by the builtin loads and the inline-asm loads / stores
     // far granule rows: a ring of four columns.  The waves that consume them run one barrier behind their
     // owner wave, so a workgroup can still be reading column j - 1 while a faster one publishes column j + 1.
-    const u4 d_far = raw_desc(far, 4u * G * PC_COLS * (unsigned)sizeof(XGran));
-    __amdgpu_buffer_rsrc_t r_rec = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * G * PX_REC, 0x00020000);
-    __amdgpu_buffer_rsrc_t r_far =
+    const __amdgpu_buffer_rsrc_t r_rec = __builtin_amdgcn_make_buffer_rsrc(rec, 0, 2 * G * PX_REC, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_far =
         __builtin_amdgcn_make_buffer_rsrc(far, 0, 4 * G * PC_COLS * (int)sizeof(XGran), 0x00020000);
+#define d_rec r_rec
+#define d_far r_far
 
     // ---- load the slice (rows >= m and columns >= jb read as zero)
     T a[RT][WC];
@@ -185,7 +177,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
     // (the budget at two waves per SIMD is 256 registers either way).  s_nop: a store wider than 64 bits reads its
     // data registers for two more cycles.
     auto store16 = [&](const unsigned lo, const unsigned hi, const unsigned z, const unsigned w, const int off,
-                       const u4 &desc) __attribute__((always_inline)) {
+                       const __amdgpu_buffer_rsrc_t &desc) __attribute__((always_inline)) {
 #define LSX_ST16(R0, R1, R2, R3, POL)                                                                                   \
     asm volatile("v_mov_b32 v" #R0 ", %0\n\tv_mov_b32 v" #R1 ", %1\n\tv_mov_b32 v" #R2 ", %2\n\tv_mov_b32 v" #R3 ", %3\n\t"    \
                  "buffer_store_dwordx4 v[" #R0 ":" #R3 "], %4, %5, 0 offen" POL "\n\ts_nop 1"                             \
@@ -205,7 +197,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
                 ((jn & 1) * G + g) * PX_REC, d_rec);
     };
     // granule of column jn: {value bits, epoch jn + 1, 0}
-    auto store_gran = [&](const u4 &desc, const int off, const T v, const int jn) __attribute__((always_inline)) {
+    auto store_gran = [&](const __amdgpu_buffer_rsrc_t &desc, const int off, const T v, const int jn) __attribute__((always_inline)) {
         unsigned lo, hi;
         if (sizeof(T) == 8) { lo = (unsigned)__double2loint((double)v); hi = (unsigned)__double2hiint((double)v); }
         else { lo = __float_as_uint((float)v); hi = 0u; }
@@ -287,11 +279,11 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         constexpr int CLO = decltype(CLOt)::value, NC = decltype(NCt)::value;
         const int off = (((j & 3) * G + bg) * PC_COLS + c0 + CLO + (lane & (NC - 1))) * (int)sizeof(XGran);
         u4 v;
-        int spins = failed ? SPIN_LIMIT : 0;
+        int spins = failed ? spin_limit : 0;
         for (;;) {
             v = __builtin_amdgcn_raw_buffer_load_b128(r_far, off, opaque_zero(), 16);
             if (!__any(v.z != (unsigned)(j + 1))) break;
-            if (++spins > SPIN_LIMIT) return false;
+            if (++spins > spin_limit) return false;
         }
         T l[RT];
 #pragma unroll
@@ -393,9 +385,9 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         absorb(hA);
         if (__any(pend)) {
             if (TWO) { wait_b(); absorb(hB); }
-            int spins = failed ? SPIN_LIMIT : 0;
+            int spins = failed ? spin_limit : 0;
             while (__any(pend)) {
-                if (++spins > SPIN_LIMIT) { failed_now = true; break; }
+                if (++spins > spin_limit) { failed_now = true; break; }
                 const u4 h = __builtin_amdgcn_raw_buffer_load_b128(
                     r_rec, (par * G + (lane < G ? lane : 0)) * PX_REC, opaque_zero(), 16);
                 absorb(h);
@@ -438,7 +430,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             for (;;) {
                 const int q = lane & 7;
                 if (!__any((q > JC) & (nq.z != (unsigned)(j + 1)))) break;
-                if (++spins > SPIN_LIMIT) { failed_now = true; break; }
+                if (++spins > spin_limit) { failed_now = true; break; }
                 nq = __builtin_amdgcn_raw_buffer_load_b128(r_rec, noff, opaque_zero(), 16);
             }
             upd = !failed_now;
@@ -521,6 +513,8 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
     if (DBG && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&dbg[g * 16 + i], seg[i]);
 #undef STAMP
+#undef d_rec
+#undef d_far
     __syncthreads();
     if (tid == NT - 1) replay(jb - 1);   // the keeper recorded s_hist[jb - 1]; only its replay is left
     // a workgroup whose exchange timed out reports it through info (negative = protocol failure):
@@ -580,9 +574,15 @@ template <typename T, int RT, bool DBG>
 __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int jb, T *__restrict__ P, int ldp, int row0, int col0,
                                                         int32_t *__restrict__ ipiv, int *__restrict__ info,
                                                         char *rec, XGran *far, int *status, unsigned long long *dbg,
-                                                        int2 *__restrict__ moves, int *xcc, int *xcc_word) {
+                                                        int2 *__restrict__ moves, int *xcc, int *xcc_word,
+                                                        int spin_limit) {
     if (blockIdx.x & 7) return;
     const int G = gridDim.x >> 3, g = blockIdx.x >> 3;
+    if (spin_limit < 0) {   // fault injection (tests): the last participant shows up ~3 ms late, the others give up
+        spin_limit = -spin_limit;
+        if (g == G - 1 && G > 1)
+            for (int i = 0; i < 900; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     __shared__ int s_same;
     if (threadIdx.x < 64) {
         unsigned id;
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int 
         while (__any(pend)) {
             const int v = __hip_atomic_load(&xcc[lane < G ? lane : 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (pend && v != 0) { pend = false; same = v == (int)id + 1; }
-            if (++spins > SPIN_LIMIT) { same = false; break; }
+            if (++spins > spin_limit) { same = false; break; }
         }
         const bool all_same = !__any(!same);
         if (lane == 0) {
@@ -608,9 +608,9 @@ __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int 
     }
     __syncthreads();
     if (s_same)
-        panel_x_body<T, RT, DBG, true>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves);
+        panel_x_body<T, RT, DBG, true>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit);
     else
-        panel_x_body<T, RT, DBG, false>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves);
+        panel_x_body<T, RT, DBG, false>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit);
 }
 
 // bytes of one exchange area for panels of up to m rows (0: not served)
@@ -648,10 +648,10 @@ int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, 
     unsigned long long *dbg = h->panel_debug ? (unsigned long long *)(base + dbg_off) : nullptr;
     if (h->panel_debug)
         hipLaunchKernelGGL((panel_x_kernel<T, RT, true>), dim3(8 * G), dim3(PX_NT), 0, h->stream, m, jb, P, ldp, row0,
-                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word);
+                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit);
     else
         hipLaunchKernelGGL((panel_x_kernel<T, RT, false>), dim3(8 * G), dim3(PX_NT), 0, h->stream, m, jb, P, ldp, row0,
-                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word);
+                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit);
     LSX_HIP(hipGetLastError());
     h->moves_valid = true;
     return LSX_OK;

@@ -952,3 +952,38 @@ def test_getrf_dev_without_an_info_word_still_records_failures(dev):
     ipiv2, info2 = dev.getrf_(LU2)
     torch.cuda.synchronize()
     assert int(info2.item()) == 0 and torch.equal(LU, LU2) and torch.equal(ipiv, ipiv2)
+
+
+def test_panel_exchange_timeout_falls_back_to_per_column_launches(la):
+    """VERDICT r1 item 6 / ADVICE: the cooperative panel polls across workgroups, so all of them must be resident at
+    once.  (i) A filler holding 30 of the 32 CUs of the panel's XCD: the dispatcher places workgroups in order, the
+    panel simply starts when the CUs are free -- right factors, no fall-back.  (ii) A participant that shows up late
+    (fault injection: the last workgroup sleeps ~3 ms, spin limit 500): the others' bounded spins run out, the
+    factorisation reports it, and the host entry point redoes it with panel mode 0 (no workgroup waits for another)
+    -- right factors, one recorded fall-back, no hang and no LSX_ERR_INTERNAL."""
+    import torch
+
+    from linalg_solver_amd import dense, gen
+
+    h = la.default_handle()
+    n = 1500
+    A, b = gen.system(gen.U11, 5, n)
+    ref = dense.lu_factor(A)
+    before = h.get_option("panel_fallbacks")
+    h.occupy(0, 30, 200)
+    LU, ipiv, info = dense.lu_factor(A)
+    torch.cuda.synchronize()
+    assert info == 0 and np.array_equal(ipiv, ref[1]) and np.array_equal(LU, ref[0])
+    assert h.get_option("panel_fallbacks") == before
+    try:
+        h.set_option("panel_spin_limit", -500)
+        LU, ipiv, info = dense.lu_factor(A)
+        x, sinfo, _ = dense.solve(A, b)
+    finally:
+        h.set_option("panel_spin_limit", 1 << 20)
+    assert info == 0 and np.array_equal(ipiv, ref[1]) and np.array_equal(LU, ref[0])
+    assert sinfo == 0 and np.max(np.abs(A @ x - b)) / (np.max(np.abs(A)) * np.max(np.abs(x)) * n) < 1e-14
+    assert h.get_option("panel_fallbacks") == before + 2
+    # and without the fault the cooperative path is back
+    LU2, ipiv2, info2 = dense.lu_factor(A)
+    assert info2 == 0 and np.array_equal(LU2, ref[0]) and h.get_option("panel_fallbacks") == before + 2
