@@ -866,6 +866,12 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
         h->nb = value;
     } else if (!strcmp(key, "panel")) {
         LSX_ARG(value >= 0 && value <= 4);
+#ifndef LSX_DIAG_PANELS
+        if (value == 1 || value == 2) {
+            set_error("panel modes 1 and 2 (superseded kernels) are only in the diagnostic build: make DIAG=1");
+            return LSX_ERR_ARG;
+        }
+#endif
         h->panel_mode = value;
     } else if (!strcmp(key, "trsv")) {
         LSX_ARG(value == 0 || value == 1);
@@ -927,6 +933,13 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
+    else if (!strcmp(key, "diag_panels")) {
+#ifdef LSX_DIAG_PANELS
+        *value = 1;
+#else
+        *value = 0;
+#endif
+    }
     else if (!strcmp(key, "num_cu")) *value = h->num_cu;
     else { set_error("unknown option '%s'", key); return LSX_ERR_ARG; }
     return LSX_OK;

@@ -181,6 +181,7 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
         const int r = panel_pipelined<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
         if (r != 1) return r;  // 1 = shape not supported: try the older cooperative kernel
     }
+#ifdef LSX_DIAG_PANELS   // make DIAG=1: the superseded cooperative / blocked kernels as cross-checks
     if (h->panel_mode == 2) {
         const int r = panel_blocked<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
         if (r != 1) return r;  // 1 = shape not supported: try the unblocked cooperative kernel
@@ -189,6 +190,7 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
         const int r = panel_cooperative<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
         if (r != 1) return r;  // 1 = shape not supported by the cooperative kernel
     }
+#endif
     return panel_percolumn<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
 }
 

@@ -76,23 +76,32 @@ class Matrix:
         self._cols = row_len
         self._items = items
         self._src = None   # array backing (from_numpy); dropped as soon as `items` is handed out
+        self._dev = None   # device backing (from_dlpack of a tensor in HBM): a view, never copied to the host unasked
+
+    def _host(self):
+        """The array backing on the host, fetched from the device view on first need."""
+        if self._src is None and getattr(self, "_dev", None) is not None:
+            self._src = self._dev.detach().cpu().numpy()
+        return self._src
 
     @property
     def items(self) -> List[List[Any]]:
         if self._items is None:
-            self._items = self._src.tolist()
+            self._items = self._host().tolist()
             self._src = None   # the lists are mutable: from here on they are the only truth
+            self._dev = None
         return self._items
 
     @items.setter
     def items(self, value: List[List[Any]]):
         self._items = value
         self._src = None
+        self._dev = None
 
     def _array(self) -> np.ndarray:
         """fp64 image of the entries for the device (validated)."""
         if self._items is None:
-            return np.ascontiguousarray(self._src, dtype=np.float64)
+            return np.ascontiguousarray(self._host(), dtype=np.float64)
         return _as_array(self._items)
 
     # ---- container surface ------------------------------------------------
@@ -104,12 +113,14 @@ class Matrix:
 
     @property
     def rows(self) -> int:
-        return self._src.shape[0] if self._items is None else len(self._items)
+        if self._items is None:
+            return (self._dev if getattr(self, "_dev", None) is not None else self._src).shape[0]
+        return len(self._items)
 
     @property
     def cols(self) -> int:
         if self._items is None:
-            return self._src.shape[1]
+            return (self._dev if getattr(self, "_dev", None) is not None else self._src).shape[1]
         return len(self._items[0]) if self._items else self._cols
 
     def get_row(self, i: int) -> List[Any]:
@@ -147,13 +158,28 @@ class Matrix:
         m._cols = a.shape[1]
         m._items = None
         m._src = a
+        m._dev = None
         return m
 
     @classmethod
     def from_dlpack(cls, x) -> "Matrix":
-        """Any DLPack producer (torch tensor on CPU or GPU, numpy, ...) -> Matrix, copied to the host."""
-        if hasattr(x, "detach") and hasattr(x, "cpu"):      # torch: device tensors cannot go through numpy
-            return cls.from_numpy(x.detach().cpu().numpy())
+        """Any DLPack producer -> Matrix.  A 2-D floating tensor that lives in HBM (torch on the ROCm device) is kept
+        as a VIEW: solve_array / inverse_array / lu_device then run on it through the device-pointer entry points
+        (`*_dev`) and hand back device tensors, nothing crosses PCIe; the host copy and the list-of-lists are made
+        only if `.items` / `to_numpy()` are asked for.  Host producers (numpy, CPU tensors) are copied as before."""
+        if hasattr(x, "detach") and hasattr(x, "is_cuda"):
+            if x.is_cuda:
+                if x.dim() != 2 or x.shape[0] == 0:
+                    raise ValueError("from_dlpack needs a non-empty 2-D tensor")
+                if not x.dtype.is_floating_point:
+                    raise TypeError(f"from_dlpack of a device tensor needs a floating dtype, got {x.dtype}")
+                m = cls.__new__(cls)
+                m._cols = x.shape[1]
+                m._items = None
+                m._src = None
+                m._dev = x.detach()
+                return m
+            return cls.from_numpy(x.detach().numpy())
         return cls.from_numpy(np.from_dlpack(x))
 
     def to_numpy(self) -> np.ndarray:
@@ -161,10 +187,63 @@ class Matrix:
         return np.array(self._array(), copy=True)
 
     def __dlpack__(self, stream=None):
+        if getattr(self, "_dev", None) is not None:
+            return self._dev.__dlpack__(stream=stream) if stream is not None else self._dev.__dlpack__()
         return self.to_numpy().__dlpack__()
 
     def __dlpack_device__(self):
+        if getattr(self, "_dev", None) is not None:
+            return self._dev.__dlpack_device__()
         return self.to_numpy().__dlpack_device__()
+
+    # ---- device-resident twins: operands and results stay in HBM ------------------------------------
+    def _dev64(self):
+        import torch
+
+        t = self._dev
+        return t if (t.dtype == torch.float64 and t.is_contiguous()) else t.to(torch.float64).contiguous()
+
+    def lu_device(self):
+        """(LU, ipiv, info) as device tensors: P A = L U of a matrix built from a device tensor (the view is not
+        modified).  lsx_getrf_f64_dev."""
+        from .device import DeviceSolver
+
+        if getattr(self, "_dev", None) is None:
+            raise ValueError("lu_device needs a Matrix built by from_dlpack from a tensor in HBM")
+        dev = DeviceSolver(self._dev.device.index)
+        LU = self._dev64().clone()
+        ipiv, info = dev.getrf_(LU)
+        return LU, ipiv, info
+
+    def _solve_device(self, rhs):
+        import torch
+
+        from .device import DeviceSolver
+
+        A = self._dev64()
+        n = A.shape[0]
+        if A.shape[1] != n:
+            raise ValueError("solve_array needs a square matrix")
+        dev = DeviceSolver(self._dev.device.index)
+        LU = A.clone()
+        ipiv, info = dev.getrf_(LU)
+        if rhs is None:
+            X = dev.getri(LU, ipiv)
+        else:
+            B = rhs if hasattr(rhs, "is_cuda") else torch.as_tensor(np.asarray(rhs, dtype=np.float64))
+            B = B.to(device=A.device, dtype=torch.float64)
+            vec = B.dim() == 1
+            if B.shape[0] != n:
+                raise ValueError("Matrix dimensions must match")
+            X = B.reshape(n, -1).contiguous().clone()
+            dev.getrs_(LU, ipiv, X)
+            if vec:
+                X = X[:, 0]
+        # singular to working precision: the same test as the host path (smallest |pivot| against the largest entry)
+        ratio = float(LU.diagonal().abs().min() / A.abs().max().clamp_min(1e-300))
+        if int(info.item()) != 0 or not (ratio > dense.EPS64 * n):
+            return Matrix.NoSolution()
+        return X
 
     # ---- array-valued twins of the list-valued API (no O(N^2) Python objects) ----------------------
     def row_reduce_array(self, bar_col: int = None):
@@ -183,6 +262,8 @@ class Matrix:
         """Unique solution(s) of self * X = rhs for a square matrix (rhs: vector or matrix) as an ndarray;
         NoSolution() when the matrix is singular to working precision (use find_preimage_of for the
         general affine answer)."""
+        if getattr(self, "_dev", None) is not None and self._items is None:
+            return self._solve_device(rhs)   # operands in HBM: the result is a device tensor too
         A = self._array()
         if A.shape[0] != A.shape[1]:
             raise ValueError("solve_array needs a square matrix")
@@ -196,6 +277,10 @@ class Matrix:
         return X[:, 0] if vec else X
 
     def inverse_array(self) -> "np.ndarray | Matrix.NoSolution":
+        if getattr(self, "_dev", None) is not None and self._items is None:
+            if self._dev.shape[0] != self._dev.shape[1]:
+                raise ValueError("Matrix must be square to invert.")
+            return self._solve_device(None)
         A = self._array()
         if A.shape[0] != A.shape[1]:
             raise ValueError("Matrix must be square to invert.")

@@ -87,7 +87,7 @@ def main():
                 P0 = torch.empty(m, nbw, dtype=torch.float64, device="cuda")
                 dev.fill_(P0, gen.U11, 3)
                 outs = []
-                for mode, nt in ((1, 0), (3, 0), (3, 512)):
+                for mode, nt in ((4, 0), (3, 0), (3, 512)):
                     dev.h.set_option("panel", mode)
                     dev.h.set_option("panel_nt", nt)
                     P = P0.clone()
@@ -101,7 +101,7 @@ def main():
                         and outs[0][2] == outs[k][2]
                     print(f"panel3 check m={m} jb={nbw} variant={k}: {'bit-identical' if same else 'MISMATCH'} "
                           f"info={outs[k][2]}", flush=True)
-        for mode, nt in ((1, 0), (3, 512), (3, 256)):
+        for mode, nt in ((4, 0), (3, 512), (3, 256)):
             dev.h.set_option("panel", mode)
             dev.h.set_option("panel_nt", nt)
             for m in (args.n, args.n // 2, args.n // 8, 256):
@@ -350,7 +350,7 @@ def main():
         info = torch.zeros(1, dtype=torch.int32, device="cuda")
         dev.h.set_option("panel_nt", 0)
         dev.h.set_option("gemm_waves", 0)
-        for mode, rt, look, nb, kb in ((3, 4, 0, 128, 1), (3, 4, 2, 128, 1), (3, 4, 1, 128, 1), (3, 4, 0, 128, 2), (3, 4, 0, 64, 1), (3, 4, 0, 96, 1), (1, 4, 0, 128, 1)):
+        for mode, rt, look, nb, kb in ((3, 4, 0, 128, 1), (3, 4, 2, 128, 1), (3, 4, 1, 128, 1), (3, 4, 0, 128, 2), (3, 4, 0, 64, 1), (3, 4, 0, 96, 1), (4, 4, 0, 128, 1), (4, 4, 1, 128, 1)):
             if True:
                 dev.h.set_option("kblock", kb)
                 dev.h.set_option("panel", mode)
@@ -369,7 +369,7 @@ def main():
                 pr = dev.h.prof_read()
                 print(f"getrf n={n} panel={mode} rt={rt} lookahead={look} nb={nb} kblock={kb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  phases "
                       + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items()), flush=True)
-        dev.h.set_option("kblock", 1); dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 1)
+        dev.h.set_option("kblock", 1); dev.h.set_option("panel", 4); dev.h.set_option("lookahead", 1)
         dev.h.set_option("nb", 128)
 
 
