@@ -155,7 +155,8 @@ def main():
                 hbuf = t.cpu()
                 dist.broadcast(hbuf, src=src)
                 t.copy_(hbuf)
-        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast)
+        # the panel travels in 4 row chunks: receivers update each row range as it lands (dist.py)
+        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast, chunks=4)
         shards = [slu.fill(gen.U11, 1 + s) for s in range(total)]
 
         def step(i):

@@ -232,6 +232,18 @@ int lsx_fill_f64_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, doub
 int lsx_fill_f32_dev(lsx_handle_t h, int kind, uint64_t seed, int m, int n, float *dA, int lda,
                      int row_off, int col_off);
 
+/* ---- multi-GPU, one call ---------------------------------------------------------------
+ * P A = L U of an n x n matrix distributed 1-D block-cyclic by columns over ndev devices of one node: column block
+ * b (width nb = the handles' "nb" option, the same on all) lives on device b % ndev; dA[d] is device d's local
+ * matrix, all n rows of its blocks side by side, row-major with leading dimension lda[d].  handles[d] was created on
+ * device d (several handles on one device are allowed: rehearsal).  Per step the owner factors the panel and writes
+ * it to every peer directly (hipMemcpyPeerAsync per link, in row chunks that the receivers consume as they land);
+ * no torch.distributed, no collective library.  d_ipiv[d] (n entries, on device d) receives the full interchange
+ * list on every device, d_info[d] the info word.  Synchronous: returns when every device has finished.  Factors and
+ * pivots are bit-identical to lsx_getrf_f64_dev on one device. */
+int lsx_getrf_mg_f64(lsx_handle_t *handles, int ndev, int n, double *const *dA, const int *lda,
+                     int32_t *const *d_ipiv, int *const *d_info);
+
 /* ---- measurement --------------------------------------------------------- */
 /* When enabled, every kernel launch of the selected buckets is bracketed by HIP
  * events on the launch stream; lsx_prof_read sums them (synchronises).

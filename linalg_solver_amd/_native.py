@@ -80,6 +80,7 @@ _SIGS = {
     "lsx_diag_xchg_probe": [_vp, _i, _i, _i, _i, _i, _dp, _ip, _ip],
     "lsx_diag_chain_head_f32": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
     "lsx_diag_chain_head_f64": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp],
+    "lsx_getrf_mg_f64": [C.POINTER(_vp), _i, _i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_vp)],
     "lsx_diag_occupy": [_vp, _i, _i, _i],
     "lsx_diag_cu_mask_probe": [_vp, C.POINTER(C.c_uint32), _i, _i, C.POINTER(C.c_uint32)],
     "lsx_prof_enable": [_vp, _i],

@@ -1422,6 +1422,17 @@ int lsx_diag_chain_head_f64(lsx_handle_t h, int fused, int jb, const double *dT,
     return diag_chain_head<double>(h, jb, dT, ldt, dTinv, ncols, dA, lda, row0, d_moves);
 }
 
+int lsx_getrf_mg_f64(lsx_handle_t *handles, int ndev, int n, double *const *dA, const int *lda,
+                     int32_t *const *d_ipiv, int *const *d_info) {
+    if (!handles || ndev < 1 || ndev > 64 || n < 1 || !dA || !lda || !d_ipiv || !d_info) {
+        set_error("lsx_getrf_mg_f64: bad argument");
+        return LSX_ERR_ARG;
+    }
+    for (int d = 0; d < ndev; ++d)
+        if (!handles[d] || !d_ipiv[d] || !d_info[d]) { set_error("lsx_getrf_mg_f64: null handle or pointer for device %d", d); return LSX_ERR_ARG; }
+    return getrf_mg_f64(handles, ndev, n, dA, lda, d_ipiv, d_info);
+}
+
 // ---- measurement
 int lsx_prof_enable(lsx_handle_t h, int on) {
     LSX_DEVICE_GUARD(h);

@@ -235,6 +235,8 @@ int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B
                      T *inv64U, T *inv128L, T *inv128U);
 int diag_mfma_peak(lsx_handle_t h, int is_f32, int iters, int blocks_per_cu, double *tflops, double *clock_mhz);
 int diag_cu_mask_probe(lsx_handle_t h, const uint32_t *mask_words, int nwords, int nblocks, unsigned *out_host);
+int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *lda, int32_t *const *d_ipiv,
+                 int *const *d_info);
 int diag_occupy(lsx_handle_t h, int xcc, int wgs, int ms);
 int diag_xchg_probe(lsx_handle_t h, int mode, int G, int stride, int wt, int epochs, double *us_per_epoch,
                     int *xcc_ids, int *nfail);

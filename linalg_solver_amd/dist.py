@@ -34,7 +34,7 @@ import torch.distributed as dist
 
 class ShardedLU:
     def __init__(self, ops, n: int, nb: int, rank: int, world: int, dtype=torch.float64, device=None,
-                 group=None, bcast=None):
+                 group=None, bcast=None, chunks: int = 1):
         if nb < 1 or n < 1:
             raise ValueError("n and nb must be positive")
         if dtype != torch.float64:
@@ -61,6 +61,10 @@ class ShardedLU:
         self._bufs = [torch.zeros((258 + nb + n * nb,), dtype=dtype, device=self.device) for _ in range(2)]
         self._fast_swaps = hasattr(ops, "panel_moves_") and hasattr(ops, "laswp_moves_")
         self._custom_bcast = bcast is not None
+        # chunks > 1: the panel travels in that many row chunks (header + top rows first); a receiver starts its
+        # interchanges and U12 behind the first and updates each row range as its chunk lands, so the transfer of
+        # a 16 MB panel overlaps the update instead of preceding it (the C driver lsx_getrf_mg_f64 does the same)
+        self.chunks = max(1, int(chunks))
 
     # -- distribution helpers -------------------------------------------------
     def owner(self, b: int) -> int:
@@ -109,19 +113,40 @@ class ShardedLU:
         return None
 
     # -- the exchange ---------------------------------------------------------
-    def _bcast_start(self, t: torch.Tensor, src: int):
-        """Start the broadcast of one step.  RCCL: asynchronous, returns the work handle (the transfer
-        runs on the collective's own stream beside the update kernels).  A caller-supplied exchange
-        (tests, host staging) is blocking."""
-        if self._custom_bcast:
-            self._bcast(t, src)
-            return None
-        return dist.broadcast(t, src=src, group=self.group, async_op=True)
+    def _chunk_rows(self, m: int, jb: int):
+        """Row ranges [r0, r1) of the chunks of an m-row panel: multiples of 64 rows, the first holds at least the
+        top jb rows (L11)."""
+        per = max(((m + self.chunks - 1) // self.chunks + 63) // 64 * 64, jb)
+        out = []
+        for c in range(self.chunks):
+            r0, r1 = min(m, c * per), (m if c == self.chunks - 1 else min(m, (c + 1) * per))
+            out.append((r0, r1))
+        return out
+
+    def _bcast_start(self, t: torch.Tensor, src: int, m: int = 0, jb: int = 0):
+        """Start the broadcast of one step: a list with one work handle per chunk (None: done already).  RCCL:
+        asynchronous (the transfers run on the collective's own stream beside the update kernels).  A
+        caller-supplied exchange (tests, host staging) is blocking."""
+        pieces = [t]
+        if self.chunks > 1 and m > 0:
+            hdr = 258 + jb
+            pieces = [t[(0 if c == 0 else hdr + r0 * jb):hdr + r1 * jb] for c, (r0, r1) in enumerate(self._chunk_rows(m, jb))]
+        works = []
+        for piece in pieces:
+            if piece.numel() == 0:
+                works.append(None)
+            elif self._custom_bcast:
+                self._bcast(piece, src)
+                works.append(None)
+            else:
+                works.append(dist.broadcast(piece, src=src, group=self.group, async_op=True))
+        return works
 
     @staticmethod
     def _bcast_wait(work):
-        if work is not None:
-            work.wait()
+        for w in (work if isinstance(work, (list, tuple)) else [work]):
+            if w is not None:
+                w.wait()
 
     def _pack_panel(self, A, b, ipiv, info):
         """Owner: factor panel b in place and fill its broadcast buffer."""
@@ -166,9 +191,14 @@ class ShardedLU:
             ipiv[k:k + jb].copy_(buf[258:258 + jb])   # exact: row indices < 2^53
             info.copy_(buf[257:258])
 
+        works = {}   # panel -> its chunk work handles still to be waited for (receivers)
+
         def apply_panel(b, col0, col1):
             """Interchanges, U12 and trailing update of local columns [col0, col1) with panel b."""
+            pend = works.get(b)
             if col1 <= col0:
+                self._bcast_wait(pend or [])
+                works.pop(b, None)
                 return
             k, jb, m = shape(b)
             buf = buf_of(b)
@@ -180,7 +210,16 @@ class ShardedLU:
                 ops.laswp_(view, k, jb, ipiv[k:k + jb])
             U12 = A[k:k + jb, col0:col1]
             ops.trsm_lu_(panel[:jb, :], U12)
-            if m > jb:
+            if m > jb and pend and len(pend) > 1:
+                for c, (r0, r1) in enumerate(self._chunk_rows(m, jb)):   # each row range as its chunk lands
+                    self._bcast_wait(pend[c])
+                    r0 = max(r0, jb)
+                    if r1 > r0:
+                        ops.gemm_sub_(A[k + r0:k + r1, col0:col1], panel[r0:r1, :], U12)
+                works.pop(b, None)
+            elif m > jb:
+                self._bcast_wait(pend or [])
+                works.pop(b, None)
                 ops.gemm_sub_(A[k + jb:, col0:col1], panel[jb:, :], U12)
 
         def swap_left(b, ncols):
@@ -197,7 +236,7 @@ class ShardedLU:
         own0 = self.owner(0)
         if own0 == self.rank:
             self._pack_panel(A, 0, ipiv, info)
-        self._bcast_wait(self._bcast_start(buf_of(0), own0))
+        self._bcast_wait(self._bcast_start(buf_of(0), own0, *shape(0)[:0:-1]))
         if own0 != self.rank:
             unpack(0)
 
@@ -214,16 +253,82 @@ class ShardedLU:
                 w = self.widths[nxt]
                 apply_panel(b, right0, right0 + w)
                 self._pack_panel(A, b + 1, ipiv, info)
-                work = self._bcast_start(buf_of(b + 1), own_next)
+                k1, jb1, m1 = shape(b + 1)
+                work = self._bcast_start(buf_of(b + 1), own_next, m1, jb1)
                 right0 += w                                # ... then the rest of update b
             elif has_next:
-                work = self._bcast_start(buf_of(b + 1), own_next)   # receive posted before the update
+                k1, jb1, m1 = shape(b + 1)
+                work = self._bcast_start(buf_of(b + 1), own_next, m1, jb1)   # receives posted before the update
             apply_panel(b, right0, self.local_cols)
             # interchanges on the columns left of the panel (the owner's panel is already swapped)
             swap_left(b, self.offset[b] if own == self.rank else (self.offset[nxt] if nxt is not None
                                                                   else self.local_cols))
             if has_next:
-                self._bcast_wait(work)
+                if own_next == self.rank or self.chunks == 1:
+                    self._bcast_wait(work)                 # the owner: its sends; unchunked: the whole panel
+                else:
+                    self._bcast_wait(work[0])              # header + top rows; the other chunks are waited for
+                    works[b + 1] = work                    # where the update consumes them
                 if own_next != self.rank:
                     unpack(b + 1)
+        return ipiv, info
+
+
+class MultiDeviceLU:
+    """One process driving P devices through ONE C call (lsx_getrf_mg_f64, csrc/mg.hip): the same 1-D block-cyclic
+    column distribution as ShardedLU, the panel written to every peer directly over xGMI in row chunks -- no
+    torch.distributed.  `devices` lists the device index of every shard; the same index may appear several times
+    (several handles on one GPU: the rehearsal the one-GPU test box allows)."""
+
+    def __init__(self, n: int, devices, nb: int = 128):
+        import ctypes as C
+
+        from . import _native as N
+
+        self.n, self.nb, self.P = n, nb, len(devices)
+        self.devices = list(devices)
+        self.handles = [N.Handle(d) for d in self.devices]
+        for h in self.handles:
+            h.set_option("nb", nb)
+        self.nblocks = (n + nb - 1) // nb
+        self.blocks = [[b for b in range(self.nblocks) if b % self.P == d] for d in range(self.P)]
+        self.local_cols = [sum(min(nb, n - b * nb) for b in bl) for bl in self.blocks]
+        self._C, self._N = C, N
+
+    def scatter(self, full: torch.Tensor):
+        """Replicated full matrix (on any device) -> the P local matrices."""
+        out = []
+        for d in range(self.P):
+            cols = [full[:, b * self.nb:b * self.nb + min(self.nb, self.n - b * self.nb)] for b in self.blocks[d]]
+            loc = torch.cat(cols, dim=1) if cols else torch.empty(self.n, 0, dtype=full.dtype)
+            out.append(loc.to(torch.device("cuda", self.devices[d])).contiguous())
+        return out
+
+    def gather(self, locs) -> torch.Tensor:
+        full = torch.empty(self.n, self.n, dtype=locs[0].dtype, device=locs[0].device)
+        for d in range(self.P):
+            off = 0
+            for b in self.blocks[d]:
+                w = min(self.nb, self.n - b * self.nb)
+                full[:, b * self.nb:b * self.nb + w] = locs[d][:, off:off + w].to(full.device)
+                off += w
+        return full
+
+    def factor_(self, locs):
+        """In-place P A = L U of the distributed matrix.  Returns (ipiv per device, info per device)."""
+        C, N = self._C, self._N
+        P = self.P
+        ipiv = [torch.zeros(self.n, dtype=torch.int32, device=t.device) for t in locs]
+        info = [torch.zeros(1, dtype=torch.int32, device=t.device) for t in locs]
+        for t in locs:
+            if t.dtype != torch.float64 or t.stride(1) != 1:
+                raise TypeError("local matrices must be row-major fp64")
+        hs = (C.c_void_p * P)(*[h.ptr for h in self.handles])
+        dA = (C.c_void_p * P)(*[t.data_ptr() for t in locs])
+        lda = (C.c_int * P)(*[max(t.stride(0), 1) for t in locs])
+        dp = (C.c_void_p * P)(*[t.data_ptr() for t in ipiv])
+        di = (C.c_void_p * P)(*[t.data_ptr() for t in info])
+        for d in set(self.devices):
+            torch.cuda.synchronize(d)
+        N.check(self.handles[0].lib.lsx_getrf_mg_f64(hs, P, self.n, dA, lda, dp, di), "lsx_getrf_mg_f64")
         return ipiv, info

@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nb, kind):
+def _worker(rank, world, port, n, nb, kind, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, n, nb, kind):
         from cpu_ops import CpuOps
         from oracle import capi
 
-        slu = ShardedLU(CpuOps(), n, nb, rank, world, device=torch.device("cpu"))
+        slu = ShardedLU(CpuOps(), n, nb, rank, world, device=torch.device("cpu"), chunks=chunks)
         # every column block is owned exactly once
         owned = torch.zeros(slu.nblocks, dtype=torch.int32)
         for b in slu.my_blocks:
@@ -63,6 +63,14 @@ def _worker(rank, world, port, n, nb, kind):
                                              (4, 260, 32, gen.U11), (4, 97, 16, gen.INT5), (3, 64, 64, gen.U11)])
 def test_sharded_lu_matches_single_process_twin(world, n, nb, kind):
     mp.spawn(_worker, args=(world, _free_port(), n, nb, kind), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,n,nb,kind,chunks", [(2, 200, 32, gen.U11, 4), (4, 260, 32, gen.U11, 3),
+                                                    (3, 150, 16, gen.INT5, 4), (2, 40, 64, gen.U11, 4)])
+def test_sharded_lu_with_the_panel_sent_in_row_chunks(world, n, nb, kind, chunks):
+    """The chunked exchange (header + top rows first, the update consuming each row range as it lands): same
+    factors and pivots as the single-process twin, at world 2, 3 and 4."""
+    mp.spawn(_worker, args=(world, _free_port(), n, nb, kind, chunks), nprocs=world, join=True)
 
 
 def test_block_cyclic_layout_arithmetic():

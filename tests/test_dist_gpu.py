@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nb, outdir):
+def _worker(rank, world, port, n, nb, outdir, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, n, nb, outdir):
             dist.broadcast(h, src=src)
             t.copy_(h)
 
-        slu = ShardedLU(dev, n, nb, rank, world, bcast=bcast_via_host)
+        slu = ShardedLU(dev, n, nb, rank, world, bcast=bcast_via_host, chunks=chunks)
         A = slu.fill(gen.U11, 33)
         ipiv, info = slu.factor_(A)
         torch.cuda.synchronize()
@@ -54,9 +54,9 @@ def _worker(rank, world, port, n, nb, outdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,nb", [(1024, 128), (1000, 128), (640, 64)])
-def test_two_ranks_one_gpu_match_single_gpu_bit_for_bit(tmp_path, n, nb):
-    mp.spawn(_worker, args=(2, _free_port(), n, nb, str(tmp_path)), nprocs=2, join=True)
+@pytest.mark.parametrize("n,nb,chunks", [(1024, 128, 1), (1000, 128, 1), (640, 64, 1), (1000, 128, 4), (1536, 128, 3)])
+def test_two_ranks_one_gpu_match_single_gpu_bit_for_bit(tmp_path, n, nb, chunks):
+    mp.spawn(_worker, args=(2, _free_port(), n, nb, str(tmp_path), chunks), nprocs=2, join=True)
     z = np.load(tmp_path / "sharded.npz")
     import linalg_solver_amd as la
     from linalg_solver_amd import dense, gen
@@ -71,3 +71,32 @@ def test_two_ranks_one_gpu_match_single_gpu_bit_for_bit(tmp_path, n, nb):
     assert np.array_equal(z["ipiv"], ipiv)
     # same kernels, same k-order in every dot product: the shards reproduce the single-GPU bits
     assert np.array_equal(z["LU"], LU)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2, 3, 4])
+@pytest.mark.parametrize("n", [300, 1000, 2100])
+def test_single_call_multi_device_lu_matches_single_gpu(P, n):
+    """lsx_getrf_mg_f64 (one process, P shards, panel written to the peers in row chunks) rehearsed with P handles
+    on the one GPU of the test box: same factors and pivots, bit for bit, as the single-GPU factorisation."""
+    import torch
+
+    from linalg_solver_amd import gen
+    from linalg_solver_amd.device import DeviceSolver
+    from linalg_solver_amd.dist import MultiDeviceLU
+
+    dev = DeviceSolver()
+    A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    dev.fill_(A0, gen.U11, 70 + n)
+    ref = A0.clone()
+    ipiv_ref, info_ref = dev.getrf_(ref)
+    torch.cuda.synchronize()
+    mg = MultiDeviceLU(n, [0] * P)
+    locs = mg.scatter(A0)
+    ipiv, info = mg.factor_(locs)
+    torch.cuda.synchronize()
+    full = mg.gather(locs)
+    assert all(int(i.item()) == 0 for i in info) and int(info_ref.item()) == 0
+    for p in ipiv:
+        assert torch.equal(p, ipiv_ref)
+    assert torch.equal(full, ref)
