@@ -426,6 +426,30 @@ def main():
                                "tolerance": 1e-4, "info": int(info5.item())}
         del A64, Xd, X0, LU5, A32
     if world == 1 and not args.no_extras and args.dtype == "f64":
+        # SURVEY 8f item 1 at scale: rank-revealing row reduction of an 8192 x 8192 matrix of rank 4096 (blocked
+        # column-skip elimination + blocked back substitution); pivots against the planted structure
+        from linalg_solver_amd import _native as _N
+        nr, rk = 8192, 4096
+        Bm = torch.empty(nr, rk, dtype=torch.float64, device="cuda")
+        Cm = torch.empty(rk, nr - rk, dtype=torch.float64, device="cuda")
+        dev.fill_(Bm, gen.U11, 3)
+        dev.fill_(Cm, gen.U11, 4)
+        Ar = torch.cat([Bm, Bm @ Cm / 64.0], dim=1).contiguous()
+        ts = []
+        for _ in range(2):
+            Rr = Ar.clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pv, rkk = dev.rref_(Rr, bar_col=nr, pivot_rule=_N.PIVOT_MAX)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        pvh = pv[:2 * rk].view(rk, 2).cpu()
+        out["rref_8192_rank4096_ms"] = min(ts) * 1e3
+        out["rref_8192_rank4096"] = {"rank": int(rkk.item()),
+                                      "pivots_match_planted": bool(int(rkk.item()) == rk and bool((pvh[:, 1] == torch.arange(rk)).all())),
+                                      "max_abs_err_of_reduced_block": float((Rr[:rk, rk:] - Cm / 64.0).abs().max())}
+        del Bm, Cm, Ar, Rr
+    if world == 1 and not args.no_extras and args.dtype == "f64":
         # config #1 (the reference's own CPU-runnable case): 64 x 64 ints in [-5,5] as floats + rhs through
         # the Matrix surface -- fast path, traced path (reference-order arithmetic + step list) and traced
         # path with every intermediate LaTeX matrix, which is what the reference spends 12.3 s on

@@ -117,7 +117,8 @@ int lsx_det_f64(lsx_handle_t h, int n, const double *A, int lda, double *sign, d
 /* General m x n reduced row echelon form over columns [0,bar_col) with the
  * remaining columns carried along (row_reduce, linalg.py:534-630).  bar_col <= 0
  * means n-1 (linalg.py:543).  pivots holds *rank pairs (row, col), 0-based.
- * Pivot tolerance: |a| <= tol counts as zero; tol < 0 selects eps*max(m,n)*max|A|.
+ * Pivot tolerance: |a| <= tol counts as zero; tol < 0 selects 32*eps*max(m,n)*max|working matrix|
+ * (the running maximum, re-evaluated as the elimination proceeds).
  * pivot_rule LSX_PIVOT_FIRST takes the first row at or below the pivot row whose
  * entry is non-zero -- the reference's rule (linalg.py:548-552), which also fixes
  * the carried-along columns of rank-deficient / tall inputs; LSX_PIVOT_MAX takes

@@ -891,6 +891,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_nt")) {
         LSX_ARG(value == 0 || value == 256 || value == 512 || value == 1024);
         h->panel_nt = value;
+    } else if (!strcmp(key, "rref_blocked")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->rref_blocked = value;
     } else if (!strcmp(key, "prof_sample")) {   // bracket every value-th launch of a profiled bucket
         LSX_ARG(value >= 1);
         h->prof.sample = value;

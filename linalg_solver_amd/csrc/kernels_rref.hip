@@ -161,9 +161,18 @@ __global__ void rref_finish_kernel(RrefState *st, int *d_rank) {
     if (d_rank) *d_rank = st->rank;
 }
 
+// blocked form for large inputs with the largest-magnitude rule (kernels_rref_blk.hip); 1 = not applicable
+template <typename T>
+int rref_blocked(lsx_handle_t h, int m, int n, int bar, T *W, int ldw, int32_t *d_pivots, int *d_rank, double tol,
+                 int pivot_rule);
+
 template <typename T>
 int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots, int *d_rank,
                 double tol, int pivot_rule) {
+    if (h->rref_blocked) {
+        const int rb = rref_blocked<T>(h, m, n, bar, R, ldr, d_pivots, d_rank, tol, pivot_rule);
+        if (rb != 1) return rb;
+    }
     ProfScope ps(h, LSX_PROF_OTHER);
     // scratch: state | prow[n] | orow[n]
     const size_t need = 256 + 2 * (size_t)n * sizeof(T);
@@ -177,7 +186,9 @@ int launch_rref(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d
     LSX_HIP(hipMemsetAsync(st, 0, sizeof(RrefState), h->stream));
     if (tol < 0 && bar > 0)
         hipLaunchKernelGGL(rref_amax_kernel<T>, dim3(256), dim3(256), 0, h->stream, m, bar, R, ldr, st);
-    const double eps_scale = (double)Real<T>::eps * (double)(m > n ? m : n);
+    // 32 eps max(m, n): the residue of a dependent column after k elimination steps is ~k eps times the running
+    // maximum with a tail; a factor of 1 put exactly-rank-517 integer products of order 1000 at rank 518
+    const double eps_scale = 32.0 * (double)Real<T>::eps * (double)(m > n ? m : n);
     hipLaunchKernelGGL(rref_init_kernel, dim3(1), dim3(1), 0, h->stream, st, tol, eps_scale);
     for (int pj = 0; pj < bar; ++pj) {
         hipLaunchKernelGGL(rref_pivot_kernel<T>, dim3(1), dim3(256), 0, h->stream, m, n, pj, pivot_rule,

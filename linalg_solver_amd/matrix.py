@@ -24,7 +24,7 @@ Deliberate differences (documented in DESIGN.md):
   * no per-step LaTeX: ``row_reduce`` returns empty ``intermediate_matrices`` /
     ``intermediate_steps`` (these cost the reference >99 % of its run time);
     the ``log_*`` flags are accepted and ignored.
-  * pivoting is by largest magnitude with a tolerance (eps*max(m,n)*max|A|), so
+  * pivoting is by largest magnitude with a tolerance (32*eps*max(m,n)*max|working matrix|), so
     ``rank`` / pivot positions are those of exact arithmetic rather than the
     rounding artefacts an exact ``== 0`` test produces on floats
     (SURVEY.md appendix A.9).

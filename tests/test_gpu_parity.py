@@ -997,3 +997,65 @@ def test_from_dlpack_of_a_device_tensor_is_a_view_not_a_copy(la):
     S[:, 3] = 0.0
     assert isinstance(la.Matrix.from_dlpack(S).solve_array(b_np), la.Matrix.NoSolution)
     assert M.items[2][3] == A_np[2, 3] and M._dev is None   # the lists, once handed out, are the only truth
+
+
+@pytest.mark.parametrize("m,n,rank,bar", [(300, 300, 300, 300), (512, 700, 200, 600), (700, 512, 333, 512),
+                                          (1000, 1000, 517, 999), (640, 900, 640, 900), (1030, 1030, 129, 1030)])
+def test_blocked_rref_matches_the_unblocked_kernel(la, m, n, rank, bar):
+    """SURVEY 8f item 1 at scale: the blocked rank-revealing row reduction (column skip inside 128-column blocks,
+    MFMA trailing updates, blocked back substitution) against the per-column kernel with the same rule:
+    identical pivot positions and rank, values to working precision, and the defining identity A = A[:, pc] R."""
+    from linalg_solver_amd import _native, dense
+
+    h = la.default_handle()
+    rng = np.random.default_rng(m * 7 + n)
+    # integer factors: the product is exact, so the rank is exactly `rank` (a float product of Gaussians sits at
+    # the tolerance's edge: its "zero" columns carry the rounding noise of the product itself)
+    A = (rng.integers(-3, 4, (m, rank)) @ rng.integers(-3, 4, (rank, n))).astype(np.float64)
+    # plant zero and dependent columns so that skips happen inside blocks
+    if n > 40:
+        A[:, 5] = 0.0
+        A[:, 17] = 2.0 * A[:, 3] - A[:, 11]
+    try:
+        h.set_option("rref_blocked", 0)
+        R0, piv0, r0 = dense.rref(A, bar_col=bar, pivot_rule=_native.PIVOT_MAX)
+        h.set_option("rref_blocked", 1)
+        R1, piv1, r1 = dense.rref(A, bar_col=bar, pivot_rule=_native.PIVOT_MAX)
+    finally:
+        h.set_option("rref_blocked", 1)
+    true_rank = np.linalg.matrix_rank(A[:, :bar])
+    assert r0 == r1 == true_rank
+    assert piv0 == piv1
+    pc = [c for _, c in piv1]
+    assert np.allclose(R1[:r1][:, pc], np.eye(r1), atol=0) and not R1[r1:, :bar].any()
+    scale = max(1.0, np.max(np.abs(R0)))
+    assert np.max(np.abs(R1 - R0)) / scale < 1e-8
+    # row space: A[:, :bar] = A[:, pc] @ R[:r, :bar]
+    assert np.max(np.abs(A[:, pc] @ R1[:r1, :bar] - A[:, :bar])) / np.max(np.abs(A)) < 1e-9
+
+
+def test_blocked_rref_8192_rank_4096(dev):
+    """8192 x 8192 of rank 4096 on the device -- pivots against the planted structure (the first
+    4096 columns are independent, every later column is a combination of them) and A = A[:, pc] R."""
+    import torch
+
+    from linalg_solver_amd import _native, gen
+
+    n, rk = 8192, 4096
+    B = torch.empty(n, rk, dtype=torch.float64, device="cuda")
+    C = torch.empty(rk, n - rk, dtype=torch.float64, device="cuda")
+    dev.fill_(B, gen.U11, 3)
+    dev.fill_(C, gen.U11, 4)
+    A = torch.cat([B, B @ C / 64.0], dim=1).contiguous()
+    R = A.clone()
+    piv, rank = dev.rref_(R, bar_col=n, pivot_rule=_native.PIVOT_MAX)
+    torch.cuda.synchronize()
+    r = int(rank.item())
+    assert r == rk
+    p = piv[:2 * r].view(r, 2).cpu().numpy()
+    assert np.array_equal(p[:, 0], np.arange(rk)) and np.array_equal(p[:, 1], np.arange(rk))
+    assert float(R[rk:, :].abs().max()) == 0.0
+    assert torch.equal(R[:rk, :rk], torch.eye(rk, dtype=torch.float64, device="cuda"))
+    # the reduced right block is the planted combination: R[:rk, rk:] = C / 64
+    assert float((R[:rk, rk:] - C / 64.0).abs().max()) < 1e-7
+    assert float((B @ R[:rk, :] - A).abs().max() / A.abs().max()) < 1e-9
