@@ -302,24 +302,24 @@ __global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) v
     }
     const int nx = avoid_xcc >= 0 ? 7 : 8;
     const int rank = (avoid_xcc >= 0 && (int)xcc > avoid_xcc) ? (int)xcc - 1 : (int)xcc;
-    const int nwg = tiles_m * tiles_n;
-    const int share = (nwg + nx - 1) / nx;
-    constexpr int GROUP = 8;
-    const int per_group = GROUP * tiles_n;
+    // An XCD's share is a vertical STRIP of tile columns, walked row by row: its U12 columns (strip width x K x
+    // sizeof(T): ~1 MB) stay in that XCD's L2 for the whole update and every L21 row block is fetched once per
+    // strip -- ~9 MB of slab traffic per XCD.  (Bands of 8 tile rows over all columns, the static kernel's order,
+    // re-read all of U12 per band and XCD: 8 MB x 8 bands; profiles/r01_pmc_gemm.json saw it as 1.2x traffic.)
     for (int q = 0; q < nx; ++q) {
         const int owner = (rank + q) % nx;
-        const int lo = owner * share, hi = min(nwg, lo + share);
+        const int c_lo = (int)((long long)owner * tiles_n / nx), c_hi = (int)((long long)(owner + 1) * tiles_n / nx);
+        const int sw = c_hi - c_lo;
+        const int hi = tiles_m * sw;
+        if (sw <= 0) continue;
         for (;;) {
-            if (threadIdx.x == 0) s_tile = lo + atomicAdd(&counters[owner], 1);
+            if (threadIdx.x == 0) s_tile = atomicAdd(&counters[owner], 1);
             __syncthreads();
             const int bid = s_tile;
             __syncthreads();   // s_tile is rewritten next trip
             if (bid >= hi) break;
-            const int group_id = bid / per_group;
-            const int first_m = group_id * GROUP;
-            const int gsize = min(tiles_m - first_m, GROUP);
-            const int tile_m = first_m + (bid % per_group) % gsize;
-            const int tile_n = (bid % per_group) / gsize;
+            const int tile_m = bid / sw;
+            const int tile_n = c_lo + bid % sw;
             gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus);
             __syncthreads();   // the tile's last LDS reads are done before the next tile's first slab is stored
         }

@@ -36,13 +36,23 @@ constexpr int PX_WC = 8;      // panel columns per wave: 8 (16 waves, 128 regist
 constexpr int PX_NT = 64 * (128 / PX_WC);
 constexpr int PX_REC = 128;   // bytes of one record: granule 0 = header, granules 1..7 = near values
 constexpr int PX_NONE = 0x7fffffff;
+// Development builds only (-DLSX_PX_SEG=k, tools/seg_panel.sh): time ONE segment of the owner step -- between
+// marks k and k+1 -- with two clock reads, so that the reads' own cost is the same for every segment.
+#ifndef LSX_PX_SEG
+#define LSX_PX_SEG -1
+#endif
+#define PX_MARK(k)                                                                  \
+    if (LSX_PX_SEG >= 0) {                                                          \
+        if (LSX_PX_SEG == (k)) seg_t0 = __builtin_amdgcn_s_memtime();               \
+        if (LSX_PX_SEG + 1 == (k)) seg_acc += __builtin_amdgcn_s_memtime() - seg_t0; \
+    }
 
 // wave-wide arg-max (largest key, lowest idx on ties); idx == PX_NONE: no candidate (key must be 0 then).
 // Returns the winning idx, wave-uniform, or PX_NONE.  All 64 lanes active.
 __device__ __forceinline__ int argmax64_fast(unsigned khi, unsigned klo, int idx) {
     const unsigned mhi = rows_max_u32<4>(row16_max_u32(khi), 0);
     const bool top = (khi == mhi) & (idx != PX_NONE);
-    const unsigned long long mask = __ballot(top);
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(top);
     if (mask == 0ull) return PX_NONE;
     if ((mask & (mask - 1ull)) == 0ull)   // the high word decides
         return __builtin_amdgcn_readlane(idx, __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask)));
@@ -87,9 +97,10 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
     const int nown = (jb + WC - 1) / WC;   // waves that own columns
 
     unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DBG: 100 MHz ticks per segment (slot 15 of dbg: XCC id)
+    unsigned long long seg_t0 = 0, seg_acc = 0;             // LSX_PX_SEG builds: shader clocks of the chosen segment
     unsigned long long tlast = 0;
 #define STAMP(i)                                                              \
-    if (DBG) {                                                                \
+    if (DBG && LSX_PX_SEG < 0) {                                              \
         const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime();      \
         seg[i] += tn_ - tlast;                                                \
         tlast = tn_;                                                          \
@@ -288,12 +299,23 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         T l[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) l[r] = s_l[j & 1][64 * r + lane];
-        const T uv = bits_value<T>(v.x, v.y);
+        // a -= l * u with u taken straight from the lane that loaded it: a DPP operand (row_newbcast: lane c of the
+        // reader's own 16-lane row; every row holds the NC granules) instead of a readlane into scalar registers per
+        // entry.  (-u) * l + a is the same fused multiply-add as a - l * u.  s_nop: a DPP read of a register the
+        // previous instruction wrote needs two wait states, which the assembler does not insert inside asm.
+        const T un = -bits_value<T>(v.x, v.y);
+        asm volatile("s_nop 1" : : "v"(un));
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const T u = readlane_t(uv, c);
 #pragma unroll
-            for (int r = 0; r < RT; ++r) a[r][CLO + c] -= l[r] * u;
+            for (int r = 0; r < RT; ++r) {
+                if (sizeof(T) == 8)
+                    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(a[r][CLO + c]) : "v"(un), "v"(l[r]), "n"(c));
+                else
+                    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                 : "+v"(a[r][CLO + c]) : "v"(un), "v"(l[r]), "n"(c));
+            }
         }
         return true;
     };
@@ -365,6 +387,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         const int par = j & 1;
         const bool more = j + 1 < jb;
         if (DBG && CJ == 0) tlast = __builtin_amdgcn_s_memrealtime();
+        PX_MARK(0)
         // ---------------- O1: all headers of column j, the winner
         bool failed_now = failed;
         bool pend = lane < G;
@@ -382,6 +405,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         // it); inside the first block only A, and it has landed: the second block's far load behind it was waited for
         constexpr bool TWO = !FIRST || JC == 0;
         if (TWO) wait_a(); else wait_b();
+        PX_MARK(1)
         absorb(hA);
         if (__any(pend)) {
             if (TWO) { wait_b(); absorb(hB); }
@@ -401,6 +425,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         const unsigned phi = (unsigned)__builtin_amdgcn_readlane((int)hhi, bg);
         const bool pneg = __builtin_amdgcn_readlane((int)hneg, bg) != 0;
         const double pabs = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+        PX_MARK(2)
         STAMP(0)
         // ---------------- O2: the winner's near granules -- issued now, consumed after the multipliers, which
         // need only |pivot| and its sign from the header
@@ -423,6 +448,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             s_l[par][64 * r + lane] = l[r];
             a[r][CJ] = (act & (((frozen >> r) & 1u) == 0u)) ? l[r] : a[r][CJ];
         }
+        PX_MARK(3)
         wait_b();   // shot B (unread when A was complete) and the granule load have landed
         bool upd = false;   // the granules are valid: the block takes the update of this column
         if (fetch) {
@@ -436,18 +462,28 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             upd = !failed_now;
         }
         STAMP(1)
-        if (upd) {
-            const T uv = bits_value<T>(nq.x, nq.y);
+        PX_MARK(4)
+        if (upd) {   // the same DPP-operand form as far_update: lane c of every 16-lane row holds granule c
+            const T un = -bits_value<T>(nq.x, nq.y);
+            asm volatile("s_nop 1" : : "v"(un));
 #pragma unroll
             for (int c = JC + 1; c < 8; ++c) {
-                const T u = readlane_t(uv, c);
 #pragma unroll
-                for (int r = 0; r < RT; ++r) a[r][CB + c] -= l[r] * u;
+                for (int r = 0; r < RT; ++r) {
+                    if (sizeof(T) == 8)
+                        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(a[r][CB + c]) : "v"(un), "v"(l[r]), "n"(c));
+                    else
+                        asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                                     : "+v"(a[r][CB + c]) : "v"(un), "v"(l[r]), "n"(c));
+                }
             }
         }
+        PX_MARK(5)
         // ---------------- O3: candidate and record of the next column (at a block end: behind the barrier)
         int cl = -1;
         if (NEAR && more) cl = choose_and_announce(std::integral_constant<int, (CJ < WC - 1 ? CJ + 1 : WC - 1)>{}, j + 1);
+        PX_MARK(6)
         const bool act2 = act & !failed_now;
         if (lane == 0) s_info[par] = make_int4(valid ? win : -1, (act2 ? 1 : 0) | (failed_now ? 2 : 0), cl, 0);
         if (failed_now && !failed) {
@@ -456,8 +492,10 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         }
         if (NEAR && more) shot_async(hA, j + 1);
         STAMP(2)
+        PX_MARK(7)
         __syncthreads();
         if (!FIRST && NEAR && more) shot_async(hB, j + 1);
+        PX_MARK(8)
         STAMP(3)
         if constexpr (FIRST) { if (more) {
             // the second block follows behind the barrier like any far block; at the end of the first block it is
@@ -512,6 +550,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
     }
     if (DBG && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&dbg[g * 16 + i], seg[i]);
+    if (DBG && LSX_PX_SEG >= 0 && lane == 0) atomicAdd(&dbg[g * 16 + 12], seg_acc);
 #undef STAMP
 #undef d_rec
 #undef d_far
