@@ -292,6 +292,22 @@ def main():
             dev.gemm_sub_(Cm, A, B)                 # algorithmic: read + write C = 2*m*m*8 B (+ A, B slabs)
         torch.cuda.synchronize()
         print(f"pmc workload done: m={m}, C bytes one way = {m * m * 8}")
+    if "pmcpanel" in args.what:
+        # workload for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`: a copy of known size (calibration), then the
+        # XCD-scope panel kernel on a 8192 x 128 panel (algorithmic: read + write the panel once = 2 * 8192 * 128 * 8 B)
+        m = 8192
+        dev.h.set_option("panel", 4)
+        big = torch.empty(m, m, dtype=torch.float64, device="cuda")
+        dev.fill_(big, gen.U11, 1)
+        bigc = big.clone()                          # calibration: reads and writes m*m*8 bytes
+        P = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+        ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+        info = torch.zeros(1, dtype=torch.int32, device="cuda")
+        for rep in range(3):
+            dev.fill_(P, gen.U11, 3 + rep)
+            dev.panel_(P, 0, ipiv, info)
+        torch.cuda.synchronize()
+        print(f"pmcpanel workload done: panel {m} x {args.nb}, bytes one way = {m * args.nb * 8}; calibration copy {m * m * 8} one way")
     if "stamps" in args.what:
         import numpy as np
         names = ["1:col update+cand", "barrier A", "2:reduce+publish", "3:bulk update", "4a:poll headers",
