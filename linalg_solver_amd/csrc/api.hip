@@ -155,10 +155,12 @@ static int ensure_partition(lsx_handle_t h, int panel_cus) {
     return LSX_OK;
 }
 
-// k0 = first column handled here (columns < k0 were factored by the sequential driver).
+// k0 = first column handled here (columns < k0 were factored by the sequential driver).  k_stop > 0: stop in
+// front of the panel that starts at column k_stop (trailing matrix fully updated, that panel not yet factored):
+// the XCD-scope driver takes over from there.
 template <typename T>
 static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv,
-                           int k0, bool want_partition) {
+                           int k0, bool want_partition, int k_stop = 0) {
     const int nb = h->nb;
     struct OnSide {  // launches inside this scope go to the given stream
         lsx_handle_t h; hipStream_t keep;
@@ -249,6 +251,18 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         T *A12 = A + (size_t)k * lda + k + jb;
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
+        if (k_stop > 0 && k + jb >= k_stop) {   // last step here: no panel ahead, the whole step on the main stream
+            LSX_HIP(hipEventRecord(h->ev_panel, side));
+            LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+            h->moves = h->moves_buf[step & 1];
+            h->moves_valid = mv_valid;
+            LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
+            LSX_TRY(apply_panel_swaps<T>(h, rest, A + k + jb, lda, k, jb, d_ipiv + k));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Akk, lda, Ti, A12, lda));
+            LSX_TRY(launch_gemm_sub<T>(h, rest, rest, jb, L21, lda, A12, lda, A22, lda));
+            LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
+            break;
+        }
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
         bool next_valid;
         {
@@ -509,10 +523,20 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     }
     if (k_end < n) {
         // XCD-scope panel (panel = 4): its own schedule, for the part of the matrix whose panels one XCD holds
-        const int xrows = 32 * 64 * (sizeof(T) == 8 ? 4 : 8);
-        if (h->panel_mode == 4 && !want_partition && !h->panel_debug && nb % 32 == 0 && k_end % 32 == 0 && n - k_end <= xrows &&
-            panel_x_area_bytes(h, n - k_end, sizeof(T)) > 0)
-            return getrf_lookahead_x<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end);
+        // (8192 rows fp64, 16384 fp32); the steps in front of that part run the shared-CU schedule with the
+        // device-scope panel (12288^2 fp64: 46.4 -> see DESIGN 6).
+        int xrows = 32 * 64 * (sizeof(T) == 8 ? 4 : 8);
+        if (h->xrows_limit > 0 && h->xrows_limit < xrows) xrows = h->xrows_limit;   // tests: hand-over at small orders
+        if (h->panel_mode == 4 && !want_partition && !h->panel_debug && nb % 32 == 0 && k_end % 32 == 0 &&
+            panel_x_area_bytes(h, n - k_end, sizeof(T)) > 0) {
+            int kx = k_end;
+            if (n - kx > xrows) kx += (n - kx - xrows + nb - 1) / nb * nb;
+            if (h->hybrid_off && kx > k_end) kx = n;
+            if (kx < n) {
+                if (kx > k_end) LSX_TRY(getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, false, kx));
+                return getrf_lookahead_x<T>(h, n, A, lda, d_ipiv, d_info, Tinv, kx);
+            }
+        }
         return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, want_partition);
     }
     return LSX_OK;
@@ -894,6 +918,12 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "rref_blocked")) {
         LSX_ARG(value == 0 || value == 1);
         h->rref_blocked = value;
+    } else if (!strcmp(key, "xrows_limit")) {   // tests: hand over to the XCD-scope driver below this many rows (0 = the kernel's limit)
+        LSX_ARG(value >= 0);
+        h->xrows_limit = value;
+    } else if (!strcmp(key, "hybrid")) {   // 0: matrices taller than one XCD holds use the shared-CU schedule throughout
+        LSX_ARG(value == 0 || value == 1);
+        h->hybrid_off = !value;
     } else if (!strcmp(key, "prof_sample")) {   // bracket every value-th launch of a profiled bucket
         LSX_ARG(value >= 1);
         h->prof.sample = value;

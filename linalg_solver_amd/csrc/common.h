@@ -115,6 +115,8 @@ struct lsx_handle_s {
     // word, [1] few-RHS solve time-outs, [2] the internal info word of a factorisation called without one
     int *dev_status = nullptr;
     int rref_blocked = 1;       // 1: large inputs with LSX_PIVOT_MAX take the blocked row reduction (option rref_blocked)
+    int xrows_limit = 0;        // option xrows_limit (tests)
+    int hybrid_off = 0;         // option hybrid=0 (measurements): no hand-over to the XCD-scope driver above its row limit
     int panel_fallbacks = 0;    // host-buffer factorisations redone with panel mode 0 after an exchange time-out
     int panel_spin_limit = 1 << 20;   // polls before the XCD-scope panel gives up on a neighbour (option: tests)
     int spin_limit = 1 << 20;   // polls before a cooperative solve gives up (option trsv_spin_limit: tests)

@@ -573,9 +573,11 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
     outs = []
     try:
         dev.h.set_option("lookahead_min", 128)
-        for mode, look in ((3, 0), (3, 1), (3, 2), (3, 3), (4, 0), (4, 1)):
+        # last entry: hand-over from the shared-CU schedule to the XCD-scope driver forced at 2/5 of the order
+        for mode, look, xl in ((3, 0, 0), (3, 1, 0), (3, 2, 0), (3, 3, 0), (4, 0, 0), (4, 1, 0), (4, 1, max(128, n * 2 // 5))):
             dev.h.set_option("panel", mode)
             dev.h.set_option("lookahead", look)
+            dev.h.set_option("xrows_limit", xl)
             LU = A0.clone()
             ipiv, info = dev.getrf_(LU)
             torch.cuda.synchronize()
@@ -585,12 +587,14 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
         dev.h.set_option("panel", DEFAULT_PANEL)
         dev.h.set_option("lookahead", 1)
         dev.h.set_option("lookahead_min", 0)
+        dev.h.set_option("xrows_limit", 0)
     for LU, ipiv in outs[1:]:
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
-@pytest.mark.parametrize("n,dtype", [(3072, "f64"), (3101, "f64"), (7168, "f64"), (7203, "f64"), (8192, "f64"), (9000, "f64"),
-                                     (4096, "f32"), (4131, "f32"), (10240, "f32"), (10307, "f32")])
+@pytest.mark.parametrize("n,dtype", [(3072, "f64"), (3101, "f64"), (7168, "f64"), (7203, "f64"), (8192, "f64"), (8320, "f64"),
+                                     (9000, "f64"), (12288, "f64"), (4096, "f32"), (4131, "f32"), (10240, "f32"), (10307, "f32"),
+                                     (16533, "f32")])
 def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
     """At and just above the orders where the look-ahead driver takes over by default (aligned and odd): same
     bits as the sequential driver, and P A = L U to working precision."""

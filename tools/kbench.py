@@ -278,6 +278,37 @@ def main():
                 print(f"getrf n={n} panel={mode} lookahead={look}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  info={int(info.item())} {same}  phases "
                       + " ".join(f"{k}={v['ms']:.2f}" for k, v in pr.items() if v['ms'] > 0), flush=True)
         dev.h.set_option("panel", 3); dev.h.set_option("lookahead", 1); dev.h.set_option("lookahead_min", 0)
+    if "hyb" in args.what:
+        # matrices taller than one XCD holds: shared-CU schedule throughout (hybrid=0) against the hand-over to the
+        # XCD-scope driver once the trailing matrix fits (hybrid=1, default); sequential driver as the reference
+        dt = torch.float32 if args.f32 else torch.float64
+        for n in (args.n,) if args.n != 8192 else (8320, 10240, 12288, 16384):
+            A0 = torch.empty(n, n, dtype=dt, device="cuda")
+            dev.fill_(A0, gen.U11, 1)
+            A = A0.clone()
+            ipiv = torch.zeros(n, dtype=torch.int32, device="cuda")
+            info = torch.zeros(1, dtype=torch.int32, device="cuda")
+            ref = None
+            dev.h.set_option("panel", 4)
+            for look, hyb in ((0, 1), (1, 0), (1, 1)):
+                dev.h.set_option("lookahead", look)
+                dev.h.set_option("hybrid", hyb)
+
+                def run():
+                    A.copy_(A0)
+                    dev.getrf_(A, ipiv, info)
+                tmin, _ = timeit(run, reps=4, warm=2)
+                tcopy, _ = timeit(lambda: A.copy_(A0), reps=3, warm=1)
+                t = tmin - tcopy
+                torch.cuda.synchronize()
+                if ref is None:
+                    ref = (A.clone(), ipiv.clone())
+                    same = "reference"
+                else:
+                    same = "bit-identical" if (torch.equal(ref[0], A) and torch.equal(ref[1], ipiv)) else "MISMATCH"
+                print(f"getrf n={n} lookahead={look} hybrid={hyb}: {t:.2f} ms  {2 / 3 * n ** 3 / t / 1e9:.2f} TFLOP/s  info={int(info.item())} {same}", flush=True)
+            del A0, A
+        dev.h.set_option("lookahead", 1); dev.h.set_option("hybrid", 1)
     if "pmc" in args.what:
         # workload for `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`: two kernels of known byte counts
         # (calibration) followed by the trailing-update kernel at LU-like shapes
