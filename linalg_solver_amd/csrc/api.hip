@@ -155,6 +155,18 @@ static int ensure_partition(lsx_handle_t h, int panel_cus) {
     return LSX_OK;
 }
 
+// On an error return inside a two-stream driver, work already queued on the side stream must not outlive the
+// call: the caller's stream waits for it (the next call on the handle, or the caller reading A, would race otherwise).
+struct JoinSide {
+    lsx_handle_t h; hipStream_t side, main_s, caller; bool armed = true;
+    ~JoinSide() {
+        if (!armed) return;
+        if (hipEventRecord(h->ev_done, side) == hipSuccess) (void)hipStreamWaitEvent(main_s, h->ev_done, 0);
+        if (caller != main_s && hipEventRecord(h->ev_start, main_s) == hipSuccess) (void)hipStreamWaitEvent(caller, h->ev_start, 0);
+        h->moves_valid = false;
+    }
+};
+
 // k0 = first column handled here (columns < k0 were factored by the sequential driver).  k_stop > 0: stop in
 // front of the panel that starts at column k_stop (trailing matrix fully updated, that panel not yet factored):
 // the XCD-scope driver takes over from there.
@@ -194,6 +206,7 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         lsx_handle_t h; hipStream_t keep; int nt, rt, mode;
         ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; h->panel_mode = mode; h->panel_area_stride = 0; h->panel_area = 0; }
     } restore{h, caller, h->panel_nt, h->panel_rt, h->panel_mode};
+    JoinSide join{h, side, main_s, caller};
     // this schedule shares the CUs between the panel and the update: the XCD-scope panel (which fills an XCD) has
     // its own driver, getrf_lookahead_x; here it would stall every launch beside it
     if (h->panel_mode == 4) h->panel_mode = 3;
@@ -313,6 +326,7 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         have_update = true;
         h->moves_valid = next_valid;
     }
+    join.armed = false;   // both streams were joined by the last step
     if (partitioned) {  // hand the result back to the caller's stream
         LSX_HIP(hipEventRecord(h->ev_done, main_s));
         LSX_HIP(hipStreamWaitEvent(caller, h->ev_done, 0));
@@ -354,6 +368,7 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             h->panel_xcc_word = nullptr;
         }
     } restore{h, main_s};
+    JoinSide join{h, side, main_s, main_s};
     char *wbase = (char *)h->scratch + 2 * area;
     int *xcc_word = (int *)wbase;                    // 1 + XCC id of the panel's XCD (blocks = 0 mod 8 land on XCC 0)
     int *pass = (int *)(wbase + 256);                // per step: update workgroups that left the panel's XCD
@@ -436,6 +451,7 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     // the last panel is factored; every panel's interchanges on the columns left of it
     LSX_HIP(hipEventRecord(h->ev_panel, side));
     LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+    join.armed = false;   // joined just above
     return launch_laswp_left_all<T>(h, A, lda, k0, nb, nsteps, h->moves_all);
 }
 

@@ -59,7 +59,15 @@ class Matrix:
     and materialises `items` only when somebody asks for it: at N >= 4096 the O(N^2) Python objects cost
     seconds, the factorisation milliseconds."""
 
-    def __init__(self, items: List[List[Any]]):
+    def __init__(self, items: List[List[Any]], *, backend: str = "auto"):
+        # SURVEY 8b's opt-in selector.  "auto" and "hip" are the same thing here -- this package IS the HIP path and
+        # ships no other; "cpu" is refused rather than served by a Python fall-back (the reference is the CPU path).
+        if backend not in ("auto", "hip"):
+            if backend == "cpu":
+                raise NotImplementedError("linalg_solver_amd has no CPU backend by design: use the reference "
+                                          "linalg_solver.Matrix for exact/symbolic or CPU-only work")
+            raise ValueError(f"unknown backend {backend!r}: expected 'auto' or 'hip'")
+        self.backend = "hip"
         # linalg.py:14-32 -- same checks, same messages
         if not items:
             raise ValueError("Matrix cannot be empty")
@@ -155,6 +163,7 @@ class Matrix:
         if a.dtype.kind not in "iuf":
             raise TypeError(f"from_numpy needs an integer or floating array, got dtype {a.dtype}")
         m = cls.__new__(cls)
+        m.backend = "hip"
         m._cols = a.shape[1]
         m._items = None
         m._src = a
@@ -174,6 +183,7 @@ class Matrix:
                 if not x.dtype.is_floating_point:
                     raise TypeError(f"from_dlpack of a device tensor needs a floating dtype, got {x.dtype}")
                 m = cls.__new__(cls)
+                m.backend = "hip"
                 m._cols = x.shape[1]
                 m._items = None
                 m._src = None

@@ -64,6 +64,16 @@ def test_non_numeric_entries_are_rejected_not_routed_to_a_cpu_path():
             call()
 
 
+def test_backend_selector_has_no_cpu_route():
+    # SURVEY 8b's opt-in selector: "auto" / "hip" are this package; "cpu" is refused, not served in Python
+    assert la.Matrix([[1, 2], [3, 4]]).backend == "hip"
+    assert la.Matrix([[1, 2], [3, 4]], backend="hip").backend == "hip"
+    with pytest.raises(NotImplementedError, match="no CPU backend"):
+        la.Matrix([[1, 2], [3, 4]], backend="cpu")
+    with pytest.raises(ValueError, match="unknown backend"):
+        la.Matrix([[1, 2], [3, 4]], backend="cuda")
+
+
 def test_result_carriers():
     s = la.Matrix.AffineSubspace([1.0, 0], la.Matrix([[-1.0], [1]]))
     assert s.get_one() == [1.0, 0] and s.dim() == 1 and s.basis() == [[-1.0, 1]]
