@@ -11,18 +11,19 @@
 //    that XCD's L2 and the polling loads bypass L1 only: one hop is 0.26 us instead of 0.50-0.56 us through
 //    the fabric.  Placement is verified by a device-scope handshake of XCC ids before column 0; a panel
 //    whose participants do not share one id runs the same code with write-through stores.
-//  * Cut.  A workgroup is 8 waves and wave w owns the sixteen panel columns [16w, 16w+16) -- two 8-column
-//    blocks -- of the workgroup's 64 RT rows (lane l: rows 64 r + l; 256 registers per lane are available at two
-//    waves per SIMD, the tile takes 128).  The wave that owns the current column -- the owner wave -- runs the
-//    chain header -> winner -> multipliers -> next candidate -> next header; the rank-1 update of the columns
-//    right of its own sixteen belongs to the other waves, which follow one barrier behind.
+//  * Cut.  A workgroup is 16 waves and wave w owns the eight panel columns [8w, 8w+8) of the workgroup's 64 RT rows
+//    (lane l: rows 64 r + l; 128 registers per lane at four waves per SIMD, the tile takes 64).  PX_WC = 16 selects
+//    the first form of this kernel, 8 waves x 16 columns with 256 registers per lane (measured slower).
+//    The wave that owns the current column -- the owner wave -- runs the chain header -> winner ->
+//    multipliers -> next candidate -> next header; the rank-1 update of the columns right of its own block belongs
+//    to the other waves, which follow one barrier behind.
 //  * Record.  A candidate is announced as ONE 128-byte record {header, 7 near granules}: the header carries
 //    |a|, the row and the SIGN of the candidate, the near granules the candidate row's entries in the rest of
 //    the current 8-column block.  With the sign in the header the owner forms 1/pivot and all its multipliers
 //    while the winner's near granules are still in flight.  Everything right of the current block is "far":
 //    published (one store per wave, the row's entries transposed across lanes through LDS) and fetched by the
-//    waves that own those columns, one barrier behind -- the owner wave's own second block included, which it
-//    brings up to date after the barrier while its header shot for the next column is in flight.
+//    waves that own those columns, one barrier behind (with PX_WC = 16 the owner wave's own second block included,
+//    which it brings up to date after the barrier while its header shot for the next column is in flight).
 //  * Arg-max.  The three-phase DPP arg-max runs its first phase only when the high word of |a| already
 //    separates the candidates (ties fall back to the full form, so the choice is unchanged).
 #include <type_traits>
