@@ -419,7 +419,6 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         // 18.5 / 7.9 (its resident workgroups take the CUs the next panel's small update needs: 27 instead of 17 us);
         // the update ordered behind that small update by an event 19.0 / 8.0 (a cross-stream hop on the chain).
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
-        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
         int queued = 0;
         if (rest > jb2) {
             h->moves = list(step);
@@ -438,6 +437,9 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             h->gemm_counters = nullptr;
             LSX_TRY(rq);
         }
+        // panel k is done with its exchange area and panel k+2 reuses it: cleared behind the update, off the path
+        // HEAD -> update start -> gate -> panel k+1
+        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
         {
             OnSide g(h, side);
@@ -916,6 +918,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "trsv")) {
         LSX_ARG(value == 0 || value == 1);
         h->trsv_mode = value;
+    } else if (!strcmp(key, "gemm_queue_test")) {
+        LSX_ARG(value >= 0 && value <= 2);
+        h->gemm_queue_test = value;
     } else if (!strcmp(key, "gemm_stagger")) {
         LSX_ARG(value >= 0 && value <= 64);
         h->gemm_stagger = value;
@@ -1389,6 +1394,17 @@ int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, 
                          const double *dB, int ldb, double *dC, int ldc) {
     LSX_DEVICE_GUARD(h);
     LSX_ARG(h && dA && dB && dC && lda >= k && ldb >= n && ldc >= n);
+    if (h->gemm_queue_test) {   // measurements: the work-queue form alone (1: all XCDs, 2: XCD 0 left out as beside a panel)
+        LSX_TRY(ensure_scratch(h, 4096));
+        int *w = (int *)h->scratch;
+        LSX_HIP(hipMemsetAsync(w, 0, 1024, h->stream));
+        if (h->gemm_queue_test == 2) LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, h->stream));
+        h->gemm_queue = 1; h->gemm_counters = w + 64; h->gemm_counter_sets = 1; h->gemm_counter_set = 0;
+        h->gemm_avoid_word = h->gemm_queue_test == 2 ? w : nullptr; h->gemm_pass_word = w + 1;
+        const int r = launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
+        h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr;
+        return r;
+    }
     return launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
 }
 int lsx_gemm_add_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, int lda,

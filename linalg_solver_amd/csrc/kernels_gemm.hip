@@ -68,11 +68,14 @@ struct ASlab {
 // unpredicated 16-byte access.  Otherwise every element is bounds-checked (edge tiles, odd ld).
 // NWN = waves along N (2 or 4): the workgroup has (BM_/64)*NWN waves, each owning a 64 x (128/NWN) piece.
 // BM_ = tile height: 128, or 64 for skinny updates (half the waves, twice the workgroups).
+// ticket_ctr != nullptr (work-queue kernel): thread 0 draws the workgroup's NEXT ticket from that counter while the
+// last slab is being multiplied and leaves it in *s_next before the C stores -- a device-scope atomic takes 2-3 us
+// to return, which drawn between two tiles would be ~10 % of a tile with nothing to cover it.
 template <typename T, bool FULL, int NWN, int BM_>
 __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__restrict__ A, int lda,
                                               const T *__restrict__ B, int ldb, T *__restrict__ C, int ldc,
                                               int m0, int n0, T (*As)[BK / 2][ASlab<T, BM_>::PAIR], T (*Bs)[BK][BN + LPAD],
-                                              int plus) {
+                                              int plus, int *ticket_ctr = nullptr, int *s_next = nullptr) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T v2 __attribute__((ext_vector_type(2)));
     constexpr int NT = BM_ * NWN;      // threads
@@ -185,9 +188,11 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     // register set in flight was tried: it spills at the 128-VGPR budget and cannot gain).
     store_slab(0, ra0, rb0);
     __syncthreads();
+    int ticket = 0;
     for (int kt = 0; kt < nslab; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nslab) load_slab((kt + 1) * BK, ra0, rb0);
+        else if (ticket_ctr && tid == 0) ticket = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
             T a[4], b[TN];
@@ -206,6 +211,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
 
     // ---- C <- accumulators.  The lane id is laundered so the row addresses are recomputed here
     // instead of being kept alive (and spilled to scratch) across the whole k-loop.
+    if (ticket_ctr && tid == 0) *s_next = ticket;
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     const int lc_e = lane_e & 15;
@@ -305,24 +311,28 @@ __global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) v
     // An XCD's share is a vertical STRIP of tile columns, walked row by row: its U12 columns (strip width x K x
     // sizeof(T): ~1 MB) stay in that XCD's L2 for the whole update and every L21 row block is fetched once per
     // strip -- ~9 MB of slab traffic per XCD.  (Bands of 8 tile rows over all columns, the static kernel's order,
-    // re-read all of U12 per band and XCD: 8 MB x 8 bands; profiles/r01_pmc_gemm.json saw it as 1.2x traffic.)
+    // re-read all of U12 per band and XCD: 8 MB x 8 bands; profiles/r01_pmc_gemm.json saw it as 1.2x traffic.
+    // In time the two orders are level -- 423 us either way at 8064^2 on all XCDs, 363 us for the static grid, of
+    // which ~28 us are the two memsets of the measurement: tools/kbench.py gemmq.)
     for (int q = 0; q < nx; ++q) {
         const int owner = (rank + q) % nx;
         const int c_lo = (int)((long long)owner * tiles_n / nx), c_hi = (int)((long long)(owner + 1) * tiles_n / nx);
         const int sw = c_hi - c_lo;
         const int hi = tiles_m * sw;
         if (sw <= 0) continue;
+        // first ticket of this queue: drawn here; the following ones are drawn inside the tile, under its last slab
+        if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(&counters[owner], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
         for (;;) {
-            if (threadIdx.x == 0) s_tile = atomicAdd(&counters[owner], 1);
-            __syncthreads();
             const int bid = s_tile;
-            __syncthreads();   // s_tile is rewritten next trip
-            if (bid >= hi) break;
+            if (bid >= hi) break;   // uniform: every thread read the same word
             const int tile_m = bid / sw;
             const int tile_n = c_lo + bid % sw;
-            gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus);
-            __syncthreads();   // the tile's last LDS reads are done before the next tile's first slab is stored
+            gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus,
+                                            &counters[owner], &s_tile);
+            __syncthreads();   // the next ticket is in s_tile; the tile's last LDS reads are done
         }
+        __syncthreads();       // everybody has read the exhausted ticket before the next queue's first one lands
     }
 }
 

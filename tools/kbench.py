@@ -58,6 +58,20 @@ def main():
                 by = 2.0 * Cm.element_size() * m * m
                 print(f"gemm_sub {str(dt)[6:]} waves={gw} m=n={m} k={k}: {tmin:.3f} ms  {fl / tmin / 1e9:.1f} TFLOP/s  "
                       f"C traffic {by / tmin / 1e6:.0f} GB/s", flush=True)
+    if "gemmq" in args.what:
+        # the work-queue form of the update alone: all XCDs / XCD 0 left out, against the plain grid
+        dt = torch.float64
+        dev.h.set_option("gemm_waves", 0)
+        for m, k in ((8064, 128), (6016, 128), (4096, 128), (2048, 128)):
+            A = torch.randn(m, k, dtype=dt, device="cuda")
+            B = torch.randn(k, m, dtype=dt, device="cuda")
+            Cm = torch.randn(m, m, dtype=dt, device="cuda")
+            for q in (0, 1, 2):
+                dev.h.set_option("gemm_queue_test", q)
+                tmin, tmed = timeit(lambda: dev.gemm_sub_(Cm, A, B), reps=7, warm=2)
+                fl = 2.0 * m * m * k
+                print(f"gemm_sub f64 m=n={m} k={k} queue={q}: min {tmin * 1e3:.1f} us  med {tmed * 1e3:.1f} us  {fl / tmin / 1e9:.1f} TFLOP/s", flush=True)
+            dev.h.set_option("gemm_queue_test", 0)
     if "panel" in args.what:
         for mode, nt, rt in ((1, 256, 4), (1, 512, 4)):
             dev.h.set_option("panel", mode)
