@@ -8,6 +8,27 @@
 
 #include "../../include/lsx.h"
 
+// Development build only (-DLSX_TSTAMP, tools/ts_lu.sh): device-clock stamps of kernel starts (first workgroup) and
+// ends (every workgroup) without a profiler attached -- rocprofv3 stretches exactly the launch gaps one wants to see.
+#ifdef LSX_TSTAMP
+static __device__ long long *lsx_ts_buf;
+struct TsScope {
+    int id;
+    __device__ void put(int tag) {
+        long long *b = lsx_ts_buf;
+        const int i = atomicAdd((int *)b, 1);
+        if (i < (1 << 20)) { b[1 + 2 * i] = tag; b[2 + 2 * i] = wall_clock64(); }
+    }
+    __device__ TsScope(int id_) : id(id_) { if (lsx_ts_buf && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) put(id); }
+    __device__ ~TsScope() { if (lsx_ts_buf && threadIdx.x == 0) put(id | 0x100); }
+};
+#define LSX_TS(id) TsScope ts_scope_(id)
+#define LSX_TS_SETTER(name) extern "C" void lsx_ts_set_##name(long long *p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(lsx_ts_buf), &p, sizeof p); }
+#else
+#define LSX_TS(id)
+#define LSX_TS_SETTER(name)
+#endif
+
 namespace lsx {
 
 void set_error(const char *fmt, ...);

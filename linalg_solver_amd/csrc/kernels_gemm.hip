@@ -248,6 +248,7 @@ __global__ __launch_bounds__(BM_ * NWN, (BM_ == 64) ? 2 : (sizeof(T) == 4 && NWN
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
                                                           int tiles_n, int tm_off, int tn_off, int plus) {
+    LSX_TS(4);
     __shared__ T As[2][BK / 2][ASlab<T, BM_>::PAIR];  // AS_AT(buf, k, m) = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
 
@@ -294,6 +295,7 @@ __global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) v
     int M, int N, int K, const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb, T *__restrict__ C,
     int ldc, int tiles_m, int tiles_n, int plus, int *__restrict__ counters, const int *__restrict__ avoid_word,
     int *__restrict__ pass_word) {
+    LSX_TS(6);
     __shared__ T As[2][BK / 2][ASlab<T, BM>::PAIR];
     __shared__ T Bs[2][BK][BN + LPAD];
     __shared__ int s_tile;
@@ -445,3 +447,5 @@ template int launch_gemm_sub<float>(lsx_handle_t, int, int, int, const float *, 
                                     int, float *, int);
 
 }  // namespace lsx
+
+LSX_TS_SETTER(gemm)

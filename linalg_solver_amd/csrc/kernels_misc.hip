@@ -184,6 +184,7 @@ template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void laswp_moves_kernel(int ncols, T *__restrict__ A, int lda, int row0,
                                                           const int2 *__restrict__ moves, int hole_at,
                                                           int hole_w) {
+    LSX_TS(8);
     laswp_moves_body<T, CW, VW>(blockIdx.x, ncols, A, lda, row0, moves, hole_at, hole_w);
 }
 
@@ -216,6 +217,7 @@ int launch_laswp_moves_around(lsx_handle_t h, int n, T *A, int lda, int row0, in
 template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void laswp_left_all_kernel(T *__restrict__ A, int lda, int k0, int nb, int nsteps,
                                                              const int2 *__restrict__ lists) {
+    LSX_TS(9);
     const int c_end = (blockIdx.x + 1) * CW * VW;   // first column right of this chunk
     for (int s = 0; s < nsteps; ++s) {
         const int ks = k0 + s * nb;
@@ -250,6 +252,7 @@ int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nst
 // (where they leave at once) BEFORE the panel's workgroups fill that XCD's CUs -- a kernel launched once they
 // are resident could not finish before the panel does, because an eighth of its workgroups is dealt to that XCD.
 __global__ __launch_bounds__(64) void gate_kernel(const int *word, int target, int limit) {
+    LSX_TS(7);
     if (threadIdx.x == 0) {
         for (int i = 0; i < limit; ++i) {
             if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
@@ -430,6 +433,7 @@ template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const T *__restrict__ Tm, int ldt,
                                                          T *__restrict__ Tinv, int ncols, T *__restrict__ A, int lda,
                                                          int row0, const int2 *__restrict__ moves) {
+    LSX_TS(2);
     if ((int)blockIdx.x < ntri)
         trtri64_body<T>(blockIdx.x, 0, 1, jb, Tm, ldt, Tinv, 0);
     else
@@ -580,6 +584,7 @@ __global__ __launch_bounds__(256) void trsm_block2_kernel(int lower, int jb, int
                                                           const T *__restrict__ Tm, int ldt,
                                                           const T *__restrict__ Tinv, T *__restrict__ B,
                                                           int ldb) {
+    LSX_TS(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BLD = CWT + 2;
     T *Bs = (T *)smem;              // [128][BLD]
@@ -1109,3 +1114,5 @@ INST(double)
 INST(float)
 
 }  // namespace lsx
+
+LSX_TS_SETTER(misc)

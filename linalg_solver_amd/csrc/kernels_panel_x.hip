@@ -617,6 +617,7 @@ __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int 
                                                         int2 *__restrict__ moves, int *xcc, int *xcc_word,
                                                         int spin_limit) {
     if (blockIdx.x & 7) return;
+    LSX_TS(1);
     const int G = gridDim.x >> 3, g = blockIdx.x >> 3;
     if (spin_limit < 0) {   // fault injection (tests): the last participant shows up ~3 ms late, the others give up
         spin_limit = -spin_limit;
@@ -701,3 +702,5 @@ template int panel_xcd<double>(lsx_handle_t, int, int, double *, int, int, int, 
 template int panel_xcd<float>(lsx_handle_t, int, int, float *, int, int, int, int32_t *, int *);
 
 }  // namespace lsx
+
+LSX_TS_SETTER(panelx)
