@@ -357,23 +357,26 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         ~OnSide() { h->stream = keep; }
     };
     const size_t area = panel_x_area_bytes(h, n - k0, sizeof(T));
-    const size_t words = pad256(256 + (size_t)nsteps * sizeof(int)) + (size_t)nsteps * 8 * sizeof(int);
-    if (area == 0 || 2 * area + words > h->scratch_bytes) { set_error("getrf_lookahead_x: scratch"); return LSX_ERR_INTERNAL; }
+    const size_t pass_bytes = pad256(256 + (size_t)nsteps * sizeof(int)), ctr_bytes = pad256((size_t)nsteps * 8 * sizeof(int));
+    const size_t words = pass_bytes + ctr_bytes + pad256((size_t)nsteps * 2 * sizeof(int));
+    if (area == 0 || 3 * area + words > h->scratch_bytes) { set_error("getrf_lookahead_x: scratch"); return LSX_ERR_INTERNAL; }
     LSX_TRY(grow(&h->moves_all, &h->moves_all_bytes, (size_t)nsteps * 2048));
     struct Restore {
         lsx_handle_t h; hipStream_t keep;
         ~Restore() {
             h->stream = keep; h->panel_area_stride = 0; h->panel_area = 0; h->moves = h->moves_buf[0];
             h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr;
-            h->panel_xcc_word = nullptr;
+            h->gemm_col0 = nullptr; h->panel_xcc_word = nullptr;
         }
     } restore{h, main_s};
     JoinSide join{h, side, main_s, main_s};
-    char *wbase = (char *)h->scratch + 2 * area;
+    // three exchange areas in rotation (panel j uses area j % 3, cleared behind update j), then the words
+    char *wbase = (char *)h->scratch + 3 * area;
     int *xcc_word = (int *)wbase;                    // 1 + XCC id of the panel's XCD (blocks = 0 mod 8 land on XCC 0)
     int *pass = (int *)(wbase + 256);                // per step: update workgroups that left the panel's XCD
-    int *counters = (int *)(wbase + pad256(256 + (size_t)nsteps * sizeof(int)));
-    LSX_HIP(hipMemsetAsync(h->scratch, 0, 2 * area + words, main_s));
+    int *counters = (int *)(wbase + pass_bytes);     // per step: the update's eight strip queues
+    int *col0 = (int *)(wbase + pass_bytes + ctr_bytes);   // per step: {ticket, finished tiles} of the update's tile column 0
+    LSX_HIP(hipMemsetAsync(h->scratch, 0, 3 * area + words, main_s));
     LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)xcc_word, 1, 1, main_s));
     h->panel_area_stride = area;
     h->panel_xcc_word = xcc_word;
@@ -388,6 +391,20 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         LSX_TRY(launch_panel<T>(h, n - k0, (n - k0) < nb ? (n - k0) : nb, A + (size_t)k0 * lda + k0, lda, k0, d_ipiv + k0, d_info));
         if (!h->moves_valid) { set_error("getrf_lookahead_x: panel without a gather list"); return LSX_ERR_INTERNAL; }
     }
+    // What the chain of step k needs from the main stream is update k-1 on the NEXT panel's columns only.  When that
+    // update went through the work queue with no edge launches, its kernel does those columns (tile column 0) first
+    // and counts their finished tiles; the chain then waits for the count inside a one-wave kernel: the panels run
+    // ahead of a long update (the first ~15 steps of an 8192^2 LU are bound by the update, which then follows
+    // back to back instead of alternating with the chain), and no gate is needed in front of a panel that leaves
+    // CUs of its XCD free -- update workgroups held up behind a running panel only delay the END of the update
+    // kernel, which nothing on the chain waits for any more.  Otherwise (ragged shapes): the event behind the whole
+    // update, and the gate.  (What this cannot buy: the chain's small kernels overlapping a RUNNING update.  The
+    // update's persistent workgroups fill every CU of seven XCDs and the hardware deals every kernel's workgroups
+    // round-robin over all eight, so a chain kernel launched early waits for update workgroups to leave:
+    // tools/ts_lu.py shows chain heads of 130 us in the first steps.)
+    const bool use_col0 = !h->x_events;
+    bool prev_col0 = false;
+    int prev_tiles = 0;
     int step = 0;
     for (int k = k0; k < n; k += nb, ++step) {
         const int jb = (n - k < nb) ? n - k : nb;
@@ -401,7 +418,10 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
         {
             OnSide g(h, side);
-            if (step > 0) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));   // update k-1 wrote the next panel's columns
+            if (step > 0) {   // update k-1 wrote the next panel's columns
+                if (prev_col0) LSX_TRY(launch_wait_count(h, col0 + 2 * (step - 1) + 1, prev_tiles));
+                else LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+            }
             h->moves = list(step);
             h->moves_valid = true;
             const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
@@ -420,6 +440,8 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         // the update ordered behind that small update by an event 19.0 / 8.0 (a cross-stream hop on the chain).
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
         int queued = 0;
+        bool cur_col0 = false;
+        int cur_tiles = 0;
         if (rest > jb2) {
             h->moves = list(step);
             h->moves_valid = true;
@@ -431,24 +453,34 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             h->gemm_counter_set = 0;
             h->gemm_avoid_word = xcc_word;
             h->gemm_pass_word = pass + step;
+            h->gemm_col0 = use_col0 ? col0 + 2 * step : nullptr;
             const int rq = launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda);
             queued = h->gemm_queue_used;
+            cur_col0 = queued && h->gemm_col0_complete;
+            cur_tiles = h->gemm_col0_tiles;
             h->gemm_queue = 0;
             h->gemm_counters = nullptr;
+            h->gemm_col0 = nullptr;
             LSX_TRY(rq);
         }
-        // panel k is done with its exchange area and panel k+2 reuses it: cleared behind the update, off the path
-        // HEAD -> update start -> gate -> panel k+1
-        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
+        // panel k is done with its exchange area and panel k+3 reuses it: cleared behind the update, off the path
+        // HEAD -> update start -> panel k+1; the chain of panel k+3 waits for (a part of) update k+1, behind this
+        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step % 3) * area, 0, area, main_s));
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
         {
             OnSide g(h, side);
-            if (queued) LSX_TRY(launch_gate(h, pass + step, 2 * h->num_cu / 8));
+            // The gate (panel k+1 not before update k has started) is still wanted while the panel takes nearly every
+            // CU of its XCD: launched earlier, it starves the main stream's small kernels in front of the update of
+            // their eighth of workgroups dealt to that XCD (8192^2, steps 2-7: 640 instead of 455 us per step).
+            const bool tall = rest > (sizeof(T) == 8 ? 6400 : 12800);
+            if (queued && (!cur_col0 || tall)) LSX_TRY(launch_gate(h, pass + step, 2 * h->num_cu / 8));
             h->moves = list(step + 1);
-            h->panel_area = (step + 1) & 1;
+            h->panel_area = (step + 1) % 3;
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
             if (!h->moves_valid) { set_error("getrf_lookahead_x: panel without a gather list"); return LSX_ERR_INTERNAL; }
         }
+        prev_col0 = cur_col0;
+        prev_tiles = cur_tiles;
     }
     // the last panel is factored; every panel's interchanges on the columns left of it
     LSX_HIP(hipEventRecord(h->ev_panel, side));
@@ -466,7 +498,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     struct MfmaOnly { lsx_handle_t h; MfmaOnly(lsx_handle_t h_) : h(h_) { h->gemm_mfma_only = true; } ~MfmaOnly() { h->gemm_mfma_only = false; } } mfma_only(h);
     // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
-                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 2 * panel_x_area_bytes(h, n, sizeof(T)) + 16384 +
+                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 3 * panel_x_area_bytes(h, n, sizeof(T)) + 16384 +
                                   ((size_t)n / 16 + 2) * 40));
     const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * sizeof(T))));   // x2: the look-ahead driver alternates
@@ -919,7 +951,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
         LSX_ARG(value == 0 || value == 1);
         h->trsv_mode = value;
     } else if (!strcmp(key, "gemm_queue_test")) {
-        LSX_ARG(value >= 0 && value <= 2);
+        LSX_ARG(value >= 0 && value <= 3);
         h->gemm_queue_test = value;
     } else if (!strcmp(key, "gemm_stagger")) {
         LSX_ARG(value >= 0 && value <= 64);
@@ -942,6 +974,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "xrows_limit")) {   // tests: hand over to the XCD-scope driver below this many rows (0 = the kernel's limit)
         LSX_ARG(value >= 0);
         h->xrows_limit = value;
+    } else if (!strcmp(key, "x_events")) {   // 1: the XCD-scope schedule orders its chain behind whole updates (events + gate)
+        LSX_ARG(value == 0 || value == 1);
+        h->x_events = value;
     } else if (!strcmp(key, "hybrid")) {   // 0: matrices taller than one XCD holds use the shared-CU schedule throughout
         LSX_ARG(value == 0 || value == 1);
         h->hybrid_off = !value;
@@ -1398,11 +1433,12 @@ int lsx_gemm_sub_f64_dev(lsx_handle_t h, int m, int n, int k, const double *dA, 
         LSX_TRY(ensure_scratch(h, 4096));
         int *w = (int *)h->scratch;
         LSX_HIP(hipMemsetAsync(w, 0, 1024, h->stream));
-        if (h->gemm_queue_test == 2) LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, h->stream));
+        if (h->gemm_queue_test >= 2) LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)w, 1, 1, h->stream));
         h->gemm_queue = 1; h->gemm_counters = w + 64; h->gemm_counter_sets = 1; h->gemm_counter_set = 0;
-        h->gemm_avoid_word = h->gemm_queue_test == 2 ? w : nullptr; h->gemm_pass_word = w + 1;
+        h->gemm_avoid_word = h->gemm_queue_test >= 2 ? w : nullptr; h->gemm_pass_word = w + 1;
+        h->gemm_col0 = h->gemm_queue_test == 3 ? w + 32 : nullptr;   // 3: with the column-0-first phase
         const int r = launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);
-        h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr;
+        h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr; h->gemm_col0 = nullptr;
         return r;
     }
     return launch_gemm_sub<double>(h, m, n, k, dA, lda, dB, ldb, dC, ldc);

@@ -104,6 +104,10 @@ struct lsx_handle_s {
     int *gemm_counters = nullptr; // gemm_counter_sets x 8 ints in scratch, zeroed by the driver
     int gemm_counter_sets = 0, gemm_counter_set = 0;
     int *gemm_pass_word = nullptr;   // incremented by every workgroup that leaves because it sits on the avoided XCD
+    int *gemm_col0 = nullptr;        // look-ahead driver: {ticket, done} words of this update's tile column 0 (zeroed by the driver)
+    int gemm_col0_tiles = 0;         // set with it: tiles in that column
+    int x_events = 0;                // option x_events (measurements, tests): no column-0 ordering in the XCD-scope schedule
+    bool gemm_col0_complete = false; // set by the last launch_gemm_*: the done word reaching tiles_m means column 0 is final
     int gemm_queue_used = 0;         // set by the last launch_gemm_*: 1 = its interior went through the queue
     void *moves_all = nullptr;       // look-ahead driver with the XCD-scope panel: one gather list per panel
     size_t moves_all_bytes = 0;
@@ -216,6 +220,7 @@ int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0);
 template <typename T>
 int launch_laswp_left_all(lsx_handle_t h, T *A, int lda, int k0, int nb, int nsteps, const void *lists);
 int launch_gate(lsx_handle_t h, const int *word, int target);
+int launch_wait_count(lsx_handle_t h, const int *word, int target);
 int launch_resid_mixed(lsx_handle_t h, int n, int nrhs, const float *A, int lda, const float *B, int ldb, const double *X,
                        int ldx, float *R, int ldr);
 int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *D, int ldd, double *X, int ldx, float *Xf,

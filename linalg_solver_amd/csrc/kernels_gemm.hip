@@ -294,7 +294,7 @@ template <typename T, int NWN>
 __global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_queue_kernel(
     int M, int N, int K, const T *__restrict__ A, int lda, const T *__restrict__ B, int ldb, T *__restrict__ C,
     int ldc, int tiles_m, int tiles_n, int plus, int *__restrict__ counters, const int *__restrict__ avoid_word,
-    int *__restrict__ pass_word) {
+    int *__restrict__ pass_word, int *__restrict__ col0) {
     LSX_TS(6);
     __shared__ T As[2][BK / 2][ASlab<T, BM>::PAIR];
     __shared__ T Bs[2][BK][BN + LPAD];
@@ -310,29 +310,42 @@ __global__ __launch_bounds__(BM * NWN, (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) v
     }
     const int nx = avoid_xcc >= 0 ? 7 : 8;
     const int rank = (avoid_xcc >= 0 && (int)xcc > avoid_xcc) ? (int)xcc - 1 : (int)xcc;
+    // col0 != nullptr (look-ahead driver): tile column 0 -- the NEXT panel's columns -- is a queue of its own that
+    // every workgroup serves first (tickets from col0[0]), and every finished tile of it is counted in col0[1]
+    // behind a device-scope fence: the panel chain waits for that count (wait_count_kernel) instead of for this
+    // whole kernel.  The other columns are shared out as below.  (One loop nest, one copy of the tile body: a separate
+    // loop for column 0 doubled the kernel, spilled, and its control flow came out of the compiler hanging.)
+    //
     // An XCD's share is a vertical STRIP of tile columns, walked row by row: its U12 columns (strip width x K x
     // sizeof(T): ~1 MB) stay in that XCD's L2 for the whole update and every L21 row block is fetched once per
     // strip -- ~9 MB of slab traffic per XCD.  (Bands of 8 tile rows over all columns, the static kernel's order,
     // re-read all of U12 per band and XCD: 8 MB x 8 bands; profiles/r01_pmc_gemm.json saw it as 1.2x traffic.
     // In time the two orders are level -- 423 us either way at 8064^2 on all XCDs, 363 us for the static grid, of
     // which ~28 us are the two memsets of the measurement: tools/kbench.py gemmq.)
-    for (int q = 0; q < nx; ++q) {
-        const int owner = (rank + q) % nx;
-        const int c_lo = (int)((long long)owner * tiles_n / nx), c_hi = (int)((long long)(owner + 1) * tiles_n / nx);
+    const int c_first = col0 ? 1 : 0;
+    const int tn = tiles_n - c_first;
+    for (int q = -c_first; q < nx; ++q) {
+        const int owner = (rank + max(q, 0)) % nx;
+        int c_lo = c_first + (int)((long long)owner * tn / nx), c_hi = c_first + (int)((long long)(owner + 1) * tn / nx);
+        int *ctr = &counters[owner];
+        if (q < 0) { c_lo = 0; c_hi = 1; ctr = col0; }
         const int sw = c_hi - c_lo;
         const int hi = tiles_m * sw;
         if (sw <= 0) continue;
         // first ticket of this queue: drawn here; the following ones are drawn inside the tile, under its last slab
-        if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(&counters[owner], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) s_tile = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         for (;;) {
             const int bid = s_tile;
             if (bid >= hi) break;   // uniform: every thread read the same word
             const int tile_m = bid / sw;
             const int tile_n = c_lo + bid % sw;
-            gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus,
-                                            &counters[owner], &s_tile);
-            __syncthreads();   // the next ticket is in s_tile; the tile's last LDS reads are done
+            gemm_sub_tile<T, true, NWN, BM>(M, N, K, A, lda, B, ldb, C, ldc, tile_m * BM, tile_n * BN, As, Bs, plus, ctr, &s_tile);
+            __syncthreads();   // the next ticket is in s_tile; the tile's last LDS reads are done, its C stores issued
+            if (q < 0 && threadIdx.x == 0) {
+                __threadfence();
+                __hip_atomic_fetch_add(col0 + 1, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();       // everybody has read the exhausted ticket before the next queue's first one lands
     }
@@ -374,6 +387,7 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
                     T *C, int ldc) {
     if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
     h->gemm_queue_used = 0;
+    h->gemm_col0_complete = false;
     const bool skinny = n < 16 && !h->gemm_mfma_only;
     const bool tiles64 = !h->gemm_queue && n >= 16 && sizeof(T) == 8 && (h->gemm_waves == 0 || h->gemm_waves == 8) && m % 64 == 0 &&
                          n % BN == 0 && k % BK == 0 && ((m + BM - 1) / BM) * (n / BN) <= h->num_cu / 2 &&
@@ -414,13 +428,16 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
         }
         if (h->gemm_queue && fm > 0 && fn > 0 && h->gemm_counters) {
             h->gemm_queue_used = 1;
+            // the column-0 count covers that column only if no edge launch below touches it
+            h->gemm_col0_complete = (h->gemm_col0 != nullptr) && fm == tm;
+            h->gemm_col0_tiles = fm;
             // interior tiles through the work queue (look-ahead driver; counters zeroed by the driver)
             const dim3 grid(2 * h->num_cu);
             int *ctr = h->gemm_counters + 8 * (h->gemm_counter_set++ % h->gemm_counter_sets);
             if (waves == 8)
-                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 4>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word);
+                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 4>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word, h->gemm_col0);
             else
-                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 2>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word);
+                hipLaunchKernelGGL((gemm_sub_queue_kernel<T, 2>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, fm, fn, plus, ctr, h->gemm_avoid_word, h->gemm_pass_word, h->gemm_col0);
         } else {
             go(true, fm, fn, 0, 0);                 // interior
         }

@@ -267,6 +267,25 @@ int launch_gate(lsx_handle_t h, const int *word, int target) {
     return LSX_OK;
 }
 
+// One wave that waits until *word >= target and, unlike the gate, must not give up quietly: the look-ahead driver
+// orders the panel chain behind the update's tile column 0 with it (gemm_sub_queue_kernel counts that column's
+// finished tiles), in place of an event behind the whole update.  A time-out (~seconds) is recorded in `status`.
+__global__ __launch_bounds__(64) void wait_count_kernel(const int *word, int target, int limit, int *status) {
+    LSX_TS(7);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < limit; ++i) {
+            if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (status) atomicMax(status, 1);
+    }
+}
+int launch_wait_count(lsx_handle_t h, const int *word, int target) {
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, h->stream, word, target, 1 << 21, h->dev_status);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
 // the same for a plain column range
 template <typename T>
 int launch_laswp_moves(lsx_handle_t h, int ncols, T *A, int lda, int row0) {

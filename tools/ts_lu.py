@@ -15,7 +15,9 @@ NAMES = {1: "panel_x", 2: "chain_head", 3: "trsm_block2", 4: "gemm_sub", 6: "gem
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ns = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+xev = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 dev = DeviceSolver()
+dev.h.set_option("x_events", xev)
 buf = torch.zeros(1 + 2 * (1 << 20), dtype=torch.int64, device="cuda")
 for name in ("panelx", "misc", "gemm"):
     fn = getattr(dev.lib, "lsx_ts_set_" + name)
@@ -68,4 +70,5 @@ if len(pan) > s0 + ns:
 gaps = [(inst[pan[i + 1]][1] - inst[pan[i]][2]) / 100.0 for i in range(len(pan) - 1)]
 durs = [(inst[p][2] - inst[p][1]) / 100.0 for p in pan]
 print(f"panel duration: mean {np.mean(durs):.1f} us (first {durs[0]:.1f}, last {durs[-1]:.1f}); panel-to-panel gap: mean {np.mean(gaps):.1f} us, median {np.median(gaps):.1f}, first 15 steps mean {np.mean(gaps[:15]):.1f}, rest {np.mean(gaps[15:]):.1f}")
+print("period per step (us): " + " ".join(f"{(inst[pan[i + 1]][1] - inst[pan[i]][1]) / 100.0:.0f}" for i in range(len(pan) - 1)))
 print(f"sum of panels {np.sum(durs) / 1e3:.2f} ms + sum of gaps {np.sum(gaps) / 1e3:.2f} ms; first panel start to last panel end {(inst[pan[-1]][2] - inst[pan[0]][1]) / 1e5:.2f} ms")
