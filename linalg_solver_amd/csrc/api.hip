@@ -418,15 +418,17 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
         {
             OnSide g(h, side);
-            if (step > 0) {   // update k-1 wrote the next panel's columns
-                if (prev_col0) LSX_TRY(launch_wait_count(h, col0 + 2 * (step - 1) + 1, prev_tiles));
-                else LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
-            }
+            // update k-1 wrote the next panel's columns: its column-0 count (waited for inside the chain head), or the
+            // event behind all of it
+            const bool counted = step > 0 && prev_col0;
+            if (step > 0 && !counted) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
             h->moves = list(step);
             h->moves_valid = true;
-            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
+            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k,
+                                                   counted ? col0 + 2 * (step - 1) + 1 : nullptr, prev_tiles);
             if (fused < 0) return fused;
             if (fused == 1) {
+                if (counted) LSX_TRY(launch_wait_count(h, col0 + 2 * (step - 1) + 1, prev_tiles));
                 LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
                 LSX_TRY(launch_laswp_moves<T>(h, jb2, A + k + jb, lda, k));
             }

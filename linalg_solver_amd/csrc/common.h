@@ -236,7 +236,8 @@ template <typename T>
 int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tinv);
 // trtri(unit lower) + gather-list interchanges on a column block in one launch; 1 = not applicable
 template <typename T>
-int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0);
+int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                      const int *wait_word = nullptr, int wait_target = 0);
 template <typename T>
 int launch_trtri_both(lsx_handle_t h, int n, const T *LU, int lda, T *invL, T *invU);
 // B (jb x ncols) <- inv(Tm) * B in place; Tinv = inverses of Tm's 64x64 diagonal blocks.

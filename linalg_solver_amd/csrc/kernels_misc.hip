@@ -448,11 +448,27 @@ __global__ __launch_bounds__(256) void trtri64_kernel(int lower, int jb, const T
 
 // Head of the look-ahead chain, one launch: the inverses of panel k's unit-lower diagonal blocks (workgroups
 // 0 .. ntri-1) and panel k's interchanges on the next panel's column block (the others) are independent.
+// wait_word != nullptr: every workgroup first waits (bounded, time-out -> *status) until *wait_word >= wait_target --
+// the count of finished tiles of the previous update's column 0 (gemm_sub_queue_kernel), i.e. the columns this
+// launch interchanges: the wait_count_kernel folded in, one launch less between two panels.
 template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const T *__restrict__ Tm, int ldt,
                                                          T *__restrict__ Tinv, int ncols, T *__restrict__ A, int lda,
-                                                         int row0, const int2 *__restrict__ moves) {
+                                                         int row0, const int2 *__restrict__ moves,
+                                                         const int *wait_word, int wait_target, int *status) {
     LSX_TS(2);
+    if (wait_word) {
+        if (threadIdx.x == 0) {
+            bool ok = false;
+            for (int i = 0; i < (1 << 21) && !ok; ++i) {
+                ok = __hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_target;
+                if (!ok) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok && status) atomicMax(status, 1);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);   // device scope: the counted tiles' stores are visible from here on
+        }
+        __syncthreads();
+    }
     if ((int)blockIdx.x < ntri)
         trtri64_body<T>(blockIdx.x, 0, 1, jb, Tm, ldt, Tinv, 0);
     else
@@ -462,14 +478,16 @@ __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const
 // trtri(lower) of the jb x jb triangle at Tm  +  the gather-list interchanges on `ncols` columns at A.
 // Returns 1 when the shapes do not allow the 16-byte path (the caller then issues the two launches).
 template <typename T>
-int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0) {
+int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                      const int *wait_word, int wait_target) {
     constexpr int VW = 16 / (int)sizeof(T);
     constexpr int CW = 32 / VW;
     if (!h->moves_valid || jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return 1;
     const int ntri = (jb + TB - 1) / TB;
     ProfScope ps(h, LSX_PROF_TRSM);
     hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
-                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)h->moves);
+                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)h->moves, wait_word, wait_target,
+                       h->dev_status);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -484,7 +502,8 @@ int diag_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int n
     if (jb <= 0 || ncols <= 0 || ((size_t)A % 16) || lda % VW || ncols % VW) return LSX_ERR_ARG;
     const int ntri = (jb + TB - 1) / TB;
     hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
-                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)moves);
+                       ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)moves, (const int *)nullptr, 0,
+                       (int *)nullptr);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -1118,7 +1137,7 @@ int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *
     template int launch_laswp_moves<T>(lsx_handle_t, int, T *, int, int);                         \
     template int launch_laswp_left_all<T>(lsx_handle_t, T *, int, int, int, int, const void *);   \
     template int launch_laswp_moves_around<T>(lsx_handle_t, int, T *, int, int, int, int);        \
-    template int launch_chain_head<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int);  \
+    template int launch_chain_head<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int, const int *, int);  \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trtri_both<T>(lsx_handle_t, int, const T *, int, T *, T *);               \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
