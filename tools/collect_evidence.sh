@@ -8,7 +8,7 @@ timeout -k 10 500 python bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/r02_bench.json
 timeout -k 10 300 python bench.py --dtype f32 --steps 10 --warmup 3 --no-cpu --no-extras > $O/bench32.log 2>&1
 tail -1 $O/bench32.log > $O/r02_bench_f32.json
-timeout -k 10 300 python tools/kbench.py mfma gemm xchg panelx lu4 > $O/r02_kbench.log 2>&1
+timeout -k 10 300 python tools/kbench.py mfma gemm gemmq xchg panelx lu4 hyb > $O/r02_kbench.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu --no-extras > $O/prof.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -- python3 $R/tools/kbench.py pmc > $O/pmc_f.log 2>&1
