@@ -952,6 +952,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "trsv")) {
         LSX_ARG(value == 0 || value == 1);
         h->trsv_mode = value;
+    } else if (!strcmp(key, "gemm_tiles32")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->gemm_no_tiles32 = !value;
     } else if (!strcmp(key, "gemm_queue_test")) {
         LSX_ARG(value >= 0 && value <= 3);
         h->gemm_queue_test = value;

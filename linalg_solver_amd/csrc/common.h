@@ -140,6 +140,7 @@ struct lsx_handle_s {
     // word, [1] few-RHS solve time-outs, [2] the internal info word of a factorisation called without one
     int *dev_status = nullptr;
     int rref_blocked = 1;       // 1: large inputs with LSX_PIVOT_MAX take the blocked row reduction (option rref_blocked)
+    int gemm_no_tiles32 = 0;    // option gemm_tiles32=0 (measurements)
     int gemm_queue_test = 0;    // option gemm_queue_test (measurements)
     int xrows_limit = 0;        // option xrows_limit (tests)
     int hybrid_off = 0;         // option hybrid=0 (measurements): no hand-over to the XCD-scope driver above its row limit

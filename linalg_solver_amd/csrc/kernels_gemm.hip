@@ -66,8 +66,10 @@ struct ASlab {
 // One 128 x 128 tile.  FULL = the tile lies inside the matrix, K is a multiple of BK and all
 // three operands are 16-byte aligned with even leading dimensions: every load/store is an
 // unpredicated 16-byte access.  Otherwise every element is bounds-checked (edge tiles, odd ld).
-// NWN = waves along N (2 or 4): the workgroup has (BM_/64)*NWN waves, each owning a 64 x (128/NWN) piece.
-// BM_ = tile height: 128, or 64 for skinny updates (half the waves, twice the workgroups).
+// NWN = waves along N (2 or 4): the workgroup has (BM_/WM)*NWN waves, each owning a WM x (128/NWN) piece, WM = 64 rows
+// (32 for the 32-row tile).
+// BM_ = tile height: 128; 64 or 32 for skinny updates (the next panel's column block: a K = 128 tile of 64 rows is
+// 6.8 us of a CU's MFMA time and 126 of them leave half the chip idle; 252 tiles of 32 rows take half that each).
 // ticket_ctr != nullptr (work-queue kernel): thread 0 draws the workgroup's NEXT ticket from that counter while the
 // last slab is being multiplied and leaves it in *s_next before the C stores -- a device-scope atomic takes 2-3 us
 // to return, which drawn between two tiles would be ~10 % of a tile with nothing to cover it.
@@ -78,7 +80,9 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
                                               int plus, int *ticket_ctr = nullptr, int *s_next = nullptr) {
     typedef typename Mfma<T>::acc_t acc_t;
     typedef T v2 __attribute__((ext_vector_type(2)));
-    constexpr int NT = BM_ * NWN;      // threads
+    constexpr int WM = BM_ < 64 ? BM_ : 64;   // rows per wave
+    constexpr int SR = WM / 16;               // 16-row MFMA tiles per wave
+    constexpr int NT = (BM_ / WM) * NWN * 64; // threads
     constexpr int WN = BN / NWN;       // wave tile width: 64 or 32
     constexpr int TN = WN / 16;        // N-tiles per wave: 4 or 2
     constexpr int NLA = BM_ * 8 / NT;  // 16-byte staging loads per thread, A slab (BM_ x 16)
@@ -86,7 +90,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = (wave / NWN) * 64, wn = (wave % NWN) * WN;
+    const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
     const int lc = lane & 15, lq = lane >> 4;
 
     // ---- staging maps
@@ -157,9 +161,9 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     load_slab(0, ra0, rb0);
 
     // ---- accumulators <- C.  Lane owns columns wn + TN*lc + t (t = N-tile index).
-    acc_t acc[4][TN];
+    acc_t acc[SR][TN];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < SR; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane, r);
@@ -195,13 +199,13 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
         else if (ticket_ctr && tid == 0) ticket = __hip_atomic_fetch_add(ticket_ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 4) {
-            T a[4], b[TN];
+            T a[SR], b[TN];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) a[s] = AS_AT(buf, kk + lq, wm + 16 * s + lc);
+            for (int s = 0; s < SR; ++s) a[s] = AS_AT(buf, kk + lq, wm + 16 * s + lc);
 #pragma unroll
             for (int t = 0; t < TN; ++t) b[t] = Bs[buf][kk + lq][wn + 16 * t + lc];
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < SR; ++s)
 #pragma unroll
                 for (int t = 0; t < TN; ++t) acc[s][t] = Mfma<T>::mma(a[s], b[t], acc[s][t]);
         }
@@ -216,7 +220,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     asm volatile("" : "+v"(lane_e));
     const int lc_e = lane_e & 15;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < SR; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm + 16 * s + Mfma<T>::crow(lane_e, r);
@@ -243,7 +247,7 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
 // (tm_off, tn_off) shift the tile grid so edge strips can be covered by separate launches.
 template <typename T, int NWN, bool FULL, int BM_ = BM>
 // waves per SIMD: 2 workgroups per CU, 3 for the fp32 8-wave form (70 VGPRs, 37 KB of LDS)
-__global__ __launch_bounds__(BM_ * NWN, (BM_ == 64) ? 2 : (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_kernel(int M, int N, int K,
+__global__ __launch_bounds__((BM_ < 64 ? 1 : BM_ / 64) * NWN * 64, (BM_ <= 64) ? 2 : (sizeof(T) == 4 && NWN == 4) ? 6 : NWN) void gemm_sub_kernel(int M, int N, int K,
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
@@ -421,8 +425,12 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
         // skinny updates (the next panel's column block in the look-ahead driver, block rows in the sharded
         // one): 128 x 128 tiles would leave most CUs idle, 64-row tiles double the workgroups
         if (tiles64) {
-            hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 64>), dim3((m / 64) * tn), dim3(256), 0, h->stream, m, n, k,
-                               A, lda, B, ldb, C, ldc, m / 64, tn, 0, 0, plus);
+            if (m % 32 == 0 && (m / 32) * tn <= h->num_cu && !h->gemm_no_tiles32)   // even skinnier: one 32-row tile per CU
+                hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 32>), dim3((m / 32) * tn), dim3(256), 0, h->stream, m, n, k,
+                                   A, lda, B, ldb, C, ldc, m / 32, tn, 0, 0, plus);
+            else
+                hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 64>), dim3((m / 64) * tn), dim3(256), 0, h->stream, m, n, k,
+                                   A, lda, B, ldb, C, ldc, m / 64, tn, 0, 0, plus);
             LSX_HIP(hipGetLastError());
             return LSX_OK;
         }
