@@ -170,7 +170,7 @@ def main():
     # launch of every phase costs ~7 % of the step; the trailing update is measured by an extra, untimed pass of
     # the same driver below (`roofline_update`), the full per-phase breakdown by a sequential step.
     dev.h.prof_reset()
-    PANEL_SAMPLE = 7 if world == 1 else 1   # every 7th panel launch (7 and the 64 panels of a step are coprime:
+    PANEL_SAMPLE = 13 if world == 1 else 1  # every 13th panel launch (13 and the 64 panels of a step are coprime:
     dev.h.set_option("prof_sample", PANEL_SAMPLE)   # over the steps every panel height is sampled): the events sit
     dev.h.prof_enable(buckets=("panel",))           # on the panel-to-panel chain and would cost 4 % if all were bracketed
     t0 = time.perf_counter()
@@ -310,6 +310,8 @@ def main():
         "phases_note": "one extra untimed step of the sequential driver (lookahead=0) with every phase bracketed by events",
     }
 
+    if g["launches"] == 0:   # sharded run: the update is not bracketed (its per-rank share is in phases_ms_per_step)
+        out["roofline_update"] = None
     gs = phases["gemm"]
     if world == 1 and gs["ms"] > 0:
         seq_tf = gs["flops"] / (gs["ms"] * 1e-3) / 1e12
