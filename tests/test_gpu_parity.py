@@ -631,6 +631,47 @@ def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
     assert res < (1e-13 if dtype == "f64" else TOL32), res
 
 
+@pytest.mark.parametrize("n,dtype", [(3200, "f64"), (4096, "f64"), (5120, "f32")])
+def test_x_schedule_orderings_and_tile_heights_agree(dev, n, dtype):
+    """The XCD-scope schedule orders its panel chain behind a COUNT of the previous update's first tile column (waited
+    for inside the chain head; option x_events=0, default) or behind an event on the whole update plus the gate
+    (x_events=1, also the form ragged orders take); the next panel's column block is updated on 32-row or 64-row
+    tiles (option gemm_tiles32).  All four combinations and the sequential driver give the same bits."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    A0 = torch.empty(n, n, dtype=tdt, device="cuda")
+    dev.fill_(A0, gen.U11, 90 + n)
+    outs = []
+    try:
+        dev.h.set_option("lookahead", 0)
+        LU = A0.clone()
+        ipiv, info = dev.getrf_(LU)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        outs.append((LU, ipiv.clone()))
+        dev.h.set_option("lookahead", 1)
+        for xev in (0, 1):
+            for t32 in (1, 0):
+                dev.h.set_option("x_events", xev)
+                dev.h.set_option("gemm_tiles32", t32)
+                LU = A0.clone()
+                ipiv, info = dev.getrf_(LU)
+                torch.cuda.synchronize()
+                assert int(info.item()) == 0
+                from linalg_solver_amd import _native
+                _native.check(dev.h.lib.lsx_check_status(dev.h.ptr), "status after the factorisation")
+                outs.append((LU, ipiv.clone()))
+    finally:
+        dev.h.set_option("lookahead", 1)
+        dev.h.set_option("x_events", 0)
+        dev.h.set_option("gemm_tiles32", 1)
+    for LU, ipiv in outs[1:]:
+        assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
+
+
 def test_lookahead_variants_are_bit_identical_at_8192(dev):
     """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
     reorders launches: the factors must not change by a single bit."""
