@@ -128,6 +128,9 @@ struct lsx_handle_s {
     size_t ws2_bytes = 0;
     void *ws3 = nullptr;     // permutation vector + right-hand-side copy
     size_t ws3_bytes = 0;
+    void *ws5 = nullptr;     // work matrix of the structured inverse (getri)
+    size_t ws5_bytes = 0;
+    int getri_plain = 0;     // option getri_structured=0: the inverse as a plain n-right-hand-side solve of P*I
     void *ws4 = nullptr;     // residual / correction of the mixed-precision solve
     size_t ws4_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
@@ -251,6 +254,8 @@ int launch_gather_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_perm, 
                        T *D, int ldd);
 template <typename T>
 int launch_set_identity_perm(lsx_handle_t h, int n, const int32_t *d_perm, T *X, int ldx);
+template <typename T>
+int launch_scatter_cols(lsx_handle_t h, int n, const int32_t *d_perm, const T *S, int lds, T *D, int ldd);
 template <typename T>
 int launch_det(lsx_handle_t h, int n, const T *LU, int lda, const int32_t *d_ipiv, double *d_out);
 template <typename T>

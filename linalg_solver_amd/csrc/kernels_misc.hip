@@ -904,12 +904,33 @@ int launch_gather_rows(lsx_handle_t h, int n, int ncols, const int32_t *d_perm, 
 
 // X (n x n) <- P (the row-permuted identity): X[i][perm[i]] = 1.  This is the
 // right-hand side of the inverse, [A|I] at linalg.py:704-706, after pivoting.
+// perm == nullptr: the identity itself
 template <typename T>
 __global__ void set_perm_identity_kernel(int n, const int32_t *__restrict__ perm, T *X, int ldx) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= n) return;
-    X[(size_t)i * ldx + j] = (perm[i] == j) ? T(1) : T(0);
+    X[(size_t)i * ldx + j] = ((perm ? perm[i] : i) == j) ? T(1) : T(0);
+}
+
+// D[:, perm[c]] = S[:, c]: the column permutation that turns U^-1 L^-1 into U^-1 L^-1 P (structured inverse, api.hip).
+// Reads are coalesced; the writes of a row stay inside that row's n * sizeof(T) bytes.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_cols_kernel(int n, const int32_t *__restrict__ perm, const T *__restrict__ S,
+                                                           int lds, T *__restrict__ D, int ldd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const int pc = perm[c];
+    for (int i = blockIdx.y; i < n; i += gridDim.y) D[(size_t)i * ldd + pc] = S[(size_t)i * lds + c];
+}
+template <typename T>
+int launch_scatter_cols(lsx_handle_t h, int n, const int32_t *d_perm, const T *S, int lds, T *D, int ldd) {
+    if (n <= 0) return LSX_OK;
+    ProfScope ps(h, LSX_PROF_OTHER);
+    hipLaunchKernelGGL(scatter_cols_kernel<T>, dim3((n + 255) / 256, n < 2048 ? n : 2048), dim3(256), 0, h->stream, n, d_perm, S, lds,
+                       D, ldd);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
 }
 
 template <typename T>
@@ -1143,6 +1164,7 @@ int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \
                                       int);                                                       \
     template int launch_set_identity_perm<T>(lsx_handle_t, int, const int32_t *, T *, int);       \
+    template int launch_scatter_cols<T>(lsx_handle_t, int, const int32_t *, const T *, int, T *, int); \
     template int launch_det<T>(lsx_handle_t, int, const T *, int, const int32_t *, double *);     \
     template int launch_copy2d<T>(lsx_handle_t, int, int, const T *, int, T *, int);              \
     template int launch_gather_rows<T>(lsx_handle_t, int, int, const int32_t *, const T *, int, T *, int); \

@@ -672,6 +672,36 @@ def test_x_schedule_orderings_and_tile_heights_agree(dev, n, dtype):
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
+@pytest.mark.parametrize("n,dtype", [(600, "f64"), (1000, "f64"), (2048, "f64"), (1537, "f32"), (4096, "f64")])
+def test_structured_inverse_equals_the_plain_solve_of_the_permuted_identity(dev, n, dtype):
+    """getri: U^-1 L^-1 P with the forward substitution restricted to the columns where L^-1 can be non-zero and the
+    column permutation applied last (4/3 n^3 flops) against the plain n-right-hand-side solve of P*I (2 n^3): the
+    skipped operations multiply exact zeros, so the two inverses agree bit for bit; A * A^-1 = I to working precision."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    A0 = torch.empty(n, n, dtype=tdt, device="cuda")
+    dev.fill_(A0, gen.U11, 17 + n)
+    LU = A0.clone()
+    ipiv, info = dev.getrf_(LU)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    invs = []
+    try:
+        for structured in (1, 0):
+            dev.h.set_option("getri_structured", structured)
+            invs.append(dev.getri(LU, ipiv).clone())
+            torch.cuda.synchronize()
+    finally:
+        dev.h.set_option("getri_structured", 1)
+    # signed zeros aside (0.0 == -0.0), the same bits
+    assert torch.equal(invs[0], invs[1])
+    R = A0.double() @ invs[0].double() - torch.eye(n, dtype=torch.float64, device="cuda")
+    assert float(R.abs().max()) < (1e-9 if dtype == "f64" else 5e-2)
+
+
 def test_lookahead_variants_are_bit_identical_at_8192(dev):
     """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
     reorders launches: the factors must not change by a single bit."""
