@@ -1176,7 +1176,7 @@ static int rref_host(lsx_handle_t h, int m, int n, int bar_col, const T *A, int 
     const int ld = ld_for(n);
     const int np = m < n ? m : n;
     LSX_TRY(ensure_ws(h, pad256(sizeof(T) * (size_t)m * ld) + pad256(sizeof(int32_t) * 2 * np) + 512));
-    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096 + (size_t)m));   // + the blocked form's row-group candidates
+    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096 + 2 * (size_t)m));   // + the blocked form's row-group candidates
     Carver c(h->ws);
     T *dR = c.take<T>((size_t)m * ld);
     int32_t *dp = c.take<int32_t>(2 * (size_t)np);
@@ -1426,7 +1426,7 @@ int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int 
     LSX_ARG(pivot_rule == LSX_PIVOT_FIRST || pivot_rule == LSX_PIVOT_MAX);
     const int bar = bar_col > 0 ? bar_col : n - 1;
     LSX_ARG(bar <= n);
-    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096 + (size_t)m));   // + the blocked form's row-group candidates
+    LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096 + 2 * (size_t)m));   // + the blocked form's row-group candidates
     return launch_rref<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol, pivot_rule);
 }
 

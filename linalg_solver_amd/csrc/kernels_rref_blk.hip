@@ -26,7 +26,7 @@ namespace lsx {
 namespace {
 
 constexpr int RB_W = 128;      // columns per block
-constexpr int RRB_ROWS = 32;   // rows per workgroup of the per-column kernels (one arg-max candidate each): with 256 the
+constexpr int RRB_ROWS = 8;    // rows per workgroup of the per-column kernels (one arg-max candidate each): with 256 the
                                // update of an 8192-row block ran on 32 CUs and took 42 us per column, 77 % of the reduction
 
 struct RrbState {
