@@ -474,7 +474,8 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             // The gate (panel k+1 not before update k has started) is still wanted while the panel takes nearly every
             // CU of its XCD: launched earlier, it starves the main stream's small kernels in front of the update of
             // their eighth of workgroups dealt to that XCD (8192^2, steps 2-7: 640 instead of 455 us per step).
-            const bool tall = rest > (sizeof(T) == 8 ? 6400 : 12800);
+            // (fp32 panels above 8192 rows keep 512 rows per workgroup: 25 of 32 CUs at 12800 rows)
+            const bool tall = (rest > 6400 && (sizeof(T) == 8 || rest <= 8192)) || rest > 12800;
             if (queued && (!cur_col0 || tall)) LSX_TRY(launch_gate(h, pass + step, 2 * h->num_cu / 8));
             h->moves = list(step + 1);
             h->panel_area = (step + 1) % 3;

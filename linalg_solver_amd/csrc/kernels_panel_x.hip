@@ -663,9 +663,8 @@ size_t panel_x_area_bytes(lsx_handle_t h, int m, size_t elem) {
 }
 
 // Returns 1 when the shape is outside what the kernel serves (caller falls back to the device-scope kernel).
-template <typename T>
-int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {
-    constexpr int RT = sizeof(T) == 8 ? 4 : 8;
+template <typename T, int RT>
+static int panel_xcd_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {
     if (jb > PC_COLS) return 1;
     const int G = (m + 64 * RT - 1) / (64 * RT);
     if (G > 32 || 8 * G > 8 * h->num_cu) return 1;
@@ -696,6 +695,14 @@ int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, 
     LSX_HIP(hipGetLastError());
     h->moves_valid = true;
     return LSX_OK;
+}
+
+// Rows per lane: 4 (256 rows per workgroup, 8192 per XCD).  fp32 has the registers for 8 (16384 rows per XCD) and
+// takes that form only for panels taller than 8192 rows: with 4 the owner wave's per-column work is half as long.
+template <typename T>
+int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {
+    if (sizeof(T) == 4 && m > 32 * 64 * 4) return panel_xcd_rt<T, sizeof(T) == 4 ? 8 : 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+    return panel_xcd_rt<T, 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
 }
 
 template int panel_xcd<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);
