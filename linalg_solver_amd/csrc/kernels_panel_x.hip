@@ -697,10 +697,15 @@ static int panel_xcd_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, 
     return LSX_OK;
 }
 
-// Rows per lane: 4 (256 rows per workgroup, 8192 per XCD).  fp32 has the registers for 8 (16384 rows per XCD) and
-// takes that form only for panels taller than 8192 rows: with 4 the owner wave's per-column work is half as long.
+// Rows per lane (RT): as few as the panel's height allows with at most 32 workgroups of 64 RT rows -- 1 up to 2048 rows,
+// 2 up to 4096, 4 up to 8192, and in fp32 (which has the registers) 8 up to 16384.  The owner wave's per-column work
+// (multipliers, update of its block, choice of the next candidate) is proportional to RT and outweighs the dearer
+// all-gather of more workgroups: 4 -> 2 -> 1 took 8192^2 fp64 from 17.1 to 16.6 to 16.3 ms and 4096^2 from 6.95 to
+// 6.36 to 6.23 ms, 8 -> 4 took 8192^2 fp32 from 16.9 to 14.5 ms.  Same arithmetic per element, same pivots.
 template <typename T>
 int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {
+    if (m <= 32 * 64 * 1) return panel_xcd_rt<T, 1>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+    if (m <= 32 * 64 * 2) return panel_xcd_rt<T, 2>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
     if (sizeof(T) == 4 && m > 32 * 64 * 4) return panel_xcd_rt<T, sizeof(T) == 4 ? 8 : 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
     return panel_xcd_rt<T, 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
 }
