@@ -513,7 +513,9 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     // 6144 +0.5 %, 7168 +5 %, 8192 +8 %, 10240..16384 +11..12 %, 20480 +10 %.  Below ~6500 the shorter update
     // no longer hides the panel and the split update costs more than it saves (fp32: see the variant choice below).
     int LOOKAHEAD_MIN = sizeof(T) == 8 ? 7168 : 10240;   // fp32: the update is half as long, break-even higher
-    if (h->panel_mode == 4) LOOKAHEAD_MIN = sizeof(T) == 8 ? 3072 : 4096;   // XCD-scope panel and its own schedule
+    // XCD-scope panel and its own schedule.  Measured against the sequential driver: fp64 1536 0 %, 2048 +2 %, 2560 +4.5 %,
+    // 3072 +7 %; fp32 (short updates) 3072 -1 %, 4096 0 %, 5120 +3 %, 6144 +7 %, 7168 +12 %.
+    if (h->panel_mode == 4) LOOKAHEAD_MIN = sizeof(T) == 8 ? 2048 : 4096;
     if (h->lookahead_min > 0) LOOKAHEAD_MIN = h->lookahead_min;                  // option (tests, tuning)
     if (const char *e = getenv("LSX_LOOKAHEAD_MIN")) {   // diagnostics
         const int v = atoi(e);

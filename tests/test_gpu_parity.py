@@ -592,7 +592,7 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
         assert torch.equal(ipiv, outs[0][1]) and torch.equal(LU, outs[0][0])
 
 
-@pytest.mark.parametrize("n,dtype", [(3072, "f64"), (3101, "f64"), (7168, "f64"), (7203, "f64"), (8192, "f64"), (8320, "f64"),
+@pytest.mark.parametrize("n,dtype", [(2048, "f64"), (2075, "f64"), (3072, "f64"), (3101, "f64"), (7168, "f64"), (7203, "f64"), (8192, "f64"), (8320, "f64"),
                                      (9000, "f64"), (12288, "f64"), (4096, "f32"), (4131, "f32"), (10240, "f32"), (10307, "f32"),
                                      (16533, "f32")])
 def test_default_driver_around_the_lookahead_thresholds(dev, n, dtype):
