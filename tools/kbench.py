@@ -72,6 +72,35 @@ def main():
                 fl = 2.0 * m * m * k
                 print(f"gemm_sub f64 m=n={m} k={k} queue={q}: min {tmin * 1e3:.1f} us  med {tmed * 1e3:.1f} us  {fl / tmin / 1e9:.1f} TFLOP/s", flush=True)
             dev.h.set_option("gemm_queue_test", 0)
+    if "panel3tall" in args.what:
+        # the device-scope panel on panels taller than one XCD holds (hybrid driver's first phase, multi-GPU): slice
+        # heights (threads per workgroup x rows per thread tile)
+        dev.h.set_option("panel", 3)
+        for m in (16384, 12288, 9216):
+            for nt, rt in ((0, 4), (256, 4), (512, 4), (512, 8), (256, 2), (512, 2)):
+                try:
+                    dev.h.set_option("panel_nt", nt)
+                    dev.h.set_option("panel_rt", rt)
+                except Exception as e:
+                    print(f"panel3 m={m} nt={nt} rt={rt}: option refused ({e})", flush=True)
+                    continue
+                P0 = torch.empty(m, args.nb, dtype=torch.float64, device="cuda")
+                dev.fill_(P0, gen.U11, 3)
+                ipiv = torch.zeros(args.nb, dtype=torch.int32, device="cuda")
+                info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                P = P0.clone()
+
+                def run():
+                    P.copy_(P0)
+                    dev.panel_(P, 0, ipiv, info)
+                try:
+                    tmin, tmed = timeit(run, reps=5, warm=2)
+                    tcopy, _ = timeit(lambda: P.copy_(P0), reps=5, warm=2)
+                    t = tmin - tcopy
+                    print(f"panel3 m={m} nt={nt} rt={rt}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col) info={int(info.item())} fallbacks(diag)={dev.h.get_option('diag_panels')}", flush=True)
+                except Exception as e:
+                    print(f"panel3 m={m} nt={nt} rt={rt}: failed ({e})", flush=True)
+        dev.h.set_option("panel_nt", 0); dev.h.set_option("panel_rt", 4); dev.h.set_option("panel", 4)
     if "panel" in args.what:
         for mode, nt, rt in ((1, 256, 4), (1, 512, 4)):
             dev.h.set_option("panel", mode)
