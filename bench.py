@@ -159,8 +159,11 @@ def main():
         slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast, chunks=4)
         shards = [slu.fill(gen.U11, 1 + s) for s in range(total)]
 
+        last = {}
+
         def step(i):
-            slu.factor_(shards[i])
+            last["ipiv"], last["info"] = slu.factor_(shards[i])
+            last["i"] = i
 
     for i in range(args.warmup):
         step(i)
@@ -216,6 +219,27 @@ def main():
         dt = float(t.item())
     if world == 1:
         assert int(info.item()) == 0, "benchmark matrix was singular"
+    shard_check = None
+    if world > 1:
+        # in-run check of the last sharded factorisation (untimed): info word, interchanges in range, and the
+        # partial-pivoting invariant |l_ij| <= 1 on this rank's columns, reduced over the ranks
+        Ash, piv = shards[last["i"]], last["ipiv"]
+        rows = torch.arange(n, device="cuda").unsqueeze(1)
+        worst = torch.zeros(1, dtype=torch.float64, device="cuda")
+        for b in slu.my_blocks:
+            o, w = slu.offset[b], slu.widths[b]
+            cols = torch.arange(b * nb, b * nb + w, device="cuda").unsqueeze(0)
+            worst = torch.maximum(worst, (Ash[:, o:o + w].abs() * (rows > cols)).max().double().reshape(1))
+        k = torch.arange(n, device="cuda", dtype=torch.int32)
+        bad = ((piv < k) | (piv >= n)).sum().double().reshape(1)
+        vec = torch.cat([worst, bad, last["info"].double().abs().reshape(1)])
+        if rehearsal:
+            hv = vec.cpu(); dist.all_reduce(hv, op=dist.ReduceOp.MAX); vec = hv
+        else:
+            dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+        shard_check = {"info": int(vec[2].item()), "max_abs_multiplier": float(vec[0].item()),
+                        "interchanges_out_of_range": int(vec[1].item()),
+                        "ok": bool(vec[2].item() == 0 and vec[1].item() == 0 and vec[0].item() <= 1.0 + 1e-12)}
 
     if rank != 0:
         if dist is not None:
@@ -312,6 +336,8 @@ def main():
 
     if g["launches"] == 0:   # sharded run: the update is not bracketed (its per-rank share is in phases_ms_per_step)
         out["roofline_update"] = None
+    if world > 1:
+        out["check"] = shard_check
     gs = phases["gemm"]
     if world == 1 and gs["ms"] > 0:
         seq_tf = gs["flops"] / (gs["ms"] * 1e-3) / 1e12
