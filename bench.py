@@ -156,7 +156,9 @@ def main():
                 dist.broadcast(hbuf, src=src)
                 t.copy_(hbuf)
         # the panel travels in 4 row chunks: receivers update each row range as it lands (dist.py)
-        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast, chunks=4)
+        # two consecutive column blocks per owner: inside a pair the next panel starts without waiting for a broadcast
+        # (the owner goes on while its panel is still on the wire), so only every second step has one on the chain
+        slu = ShardedLU(dev, n, nb, rank, world, dtype=tdt, bcast=bcast, chunks=4, dist_block=2)
         shards = [slu.fill(gen.U11, 1 + s) for s in range(total)]
 
         last = {}
@@ -296,7 +298,7 @@ def main():
         "config": {"workload": f"{n}x{n} {args.dtype} LU with partial pivoting (getrf), u11 generator, resident in HBM",
                    "n": n, "nb": nb, "panel_mode": dev.h.get_option("panel"),
                    "lookahead": look_default if world == 1 else "depth-1, sharded driver",
-                   "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic columns x{world}, panel broadcast (RCCL)"},
+                   "parallelism": "single GPU" if world == 1 else f"1-D block-cyclic columns x{world} (2 column blocks per owner), panel broadcast (RCCL) in 4 row chunks"},
         # the time-dominant kernel of the step: the panel factorisation.  SURVEY 8d prices it against HBM
         # (algorithmic bytes = each panel read + written once = 2 * sizeof(T) * m * nb per launch); what actually bounds
         # it is one cross-CU pivot exchange per column -- latency, stated beside the fraction.

@@ -34,7 +34,7 @@ import torch.distributed as dist
 
 class ShardedLU:
     def __init__(self, ops, n: int, nb: int, rank: int, world: int, dtype=torch.float64, device=None,
-                 group=None, bcast=None, chunks: int = 1):
+                 group=None, bcast=None, chunks: int = 1, dist_block: int = 1):
         if nb < 1 or n < 1:
             raise ValueError("n and nb must be positive")
         if dtype != torch.float64:
@@ -48,7 +48,11 @@ class ShardedLU:
         self._bcast = bcast if bcast is not None else (lambda t, src: dist.broadcast(t, src=src, group=self.group))
         self.nblocks = (n + nb - 1) // nb
         # global block ids owned by this rank, their widths and local column offsets
-        self.my_blocks: List[int] = [b for b in range(self.nblocks) if b % world == rank]
+        # dist_block consecutive column blocks share an owner (ScaLAPACK's distribution block > panel width): inside
+        # such a group the chain panel -> next block's update -> next panel stays on one GPU, so only every
+        # dist_block-th step has a broadcast in front of the next panel; the others send theirs beside it
+        self.dist_block = max(1, int(dist_block))
+        self.my_blocks: List[int] = [b for b in range(self.nblocks) if self.owner(b) == rank]
         self.widths = {b: min(nb, n - b * nb) for b in self.my_blocks}
         self.offset = {}
         off = 0
@@ -68,7 +72,7 @@ class ShardedLU:
 
     # -- distribution helpers -------------------------------------------------
     def owner(self, b: int) -> int:
-        return b % self.world
+        return (b // self.dist_block) % self.world
 
     def empty_local(self) -> torch.Tensor:
         return torch.empty((self.n, max(self.local_cols, 1)), dtype=self.dtype, device=self.device)
@@ -192,6 +196,15 @@ class ShardedLU:
             info.copy_(buf[257:258])
 
         works = {}   # panel -> its chunk work handles still to be waited for (receivers)
+        sends = {}   # buffer slot -> work handles of this rank's own broadcast from it, waited for only when the
+                     # slot is used again: the owner goes on with the next block (and, inside a distribution
+                     # group, the next panel) while its panel is still on the wire
+
+        def start(bb):
+            """Begin the broadcast of panel bb (send or receive) once its buffer slot is free."""
+            self._bcast_wait(sends.pop(bb & 1, None) or [])
+            kk, jj, mm = shape(bb)
+            return self._bcast_start(buf_of(bb), self.owner(bb), mm, jj)
 
         def apply_panel(b, col0, col1):
             """Interchanges, U12 and trailing update of local columns [col0, col1) with panel b."""
@@ -236,7 +249,7 @@ class ShardedLU:
         own0 = self.owner(0)
         if own0 == self.rank:
             self._pack_panel(A, 0, ipiv, info)
-        self._bcast_wait(self._bcast_start(buf_of(0), own0, *shape(0)[:0:-1]))
+        self._bcast_wait(start(0))
         if own0 != self.rank:
             unpack(0)
 
@@ -252,25 +265,28 @@ class ShardedLU:
                 assert nxt == b + 1
                 w = self.widths[nxt]
                 apply_panel(b, right0, right0 + w)
+                self._bcast_wait(sends.pop((b + 1) & 1, None) or [])   # the slot's previous broadcast has left it
                 self._pack_panel(A, b + 1, ipiv, info)
-                k1, jb1, m1 = shape(b + 1)
-                work = self._bcast_start(buf_of(b + 1), own_next, m1, jb1)
+                work = start(b + 1)
                 right0 += w                                # ... then the rest of update b
             elif has_next:
-                k1, jb1, m1 = shape(b + 1)
-                work = self._bcast_start(buf_of(b + 1), own_next, m1, jb1)   # receives posted before the update
+                work = start(b + 1)                        # receives posted before the update
             apply_panel(b, right0, self.local_cols)
             # interchanges on the columns left of the panel (the owner's panel is already swapped)
             swap_left(b, self.offset[b] if own == self.rank else (self.offset[nxt] if nxt is not None
                                                                   else self.local_cols))
             if has_next:
-                if own_next == self.rank or self.chunks == 1:
-                    self._bcast_wait(work)                 # the owner: its sends; unchunked: the whole panel
+                if own_next == self.rank:
+                    sends[(b + 1) & 1] = work              # its own sends: see `sends`
+                elif self.chunks == 1:
+                    self._bcast_wait(work)                 # unchunked: the whole panel
                 else:
                     self._bcast_wait(work[0])              # header + top rows; the other chunks are waited for
                     works[b + 1] = work                    # where the update consumes them
                 if own_next != self.rank:
                     unpack(b + 1)
+        for w_ in list(sends.values()):
+            self._bcast_wait(w_ or [])
         return ipiv, info
 
 

@@ -26,7 +26,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nb, kind, chunks=1):
+def _worker(rank, world, port, n, nb, kind, chunks=1, dist_block=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -34,7 +34,7 @@ def _worker(rank, world, port, n, nb, kind, chunks=1):
         from cpu_ops import CpuOps
         from oracle import capi
 
-        slu = ShardedLU(CpuOps(), n, nb, rank, world, device=torch.device("cpu"), chunks=chunks)
+        slu = ShardedLU(CpuOps(), n, nb, rank, world, device=torch.device("cpu"), chunks=chunks, dist_block=dist_block)
         # every column block is owned exactly once
         owned = torch.zeros(slu.nblocks, dtype=torch.int32)
         for b in slu.my_blocks:
@@ -63,6 +63,16 @@ def _worker(rank, world, port, n, nb, kind, chunks=1):
                                              (4, 260, 32, gen.U11), (4, 97, 16, gen.INT5), (3, 64, 64, gen.U11)])
 def test_sharded_lu_matches_single_process_twin(world, n, nb, kind):
     mp.spawn(_worker, args=(world, _free_port(), n, nb, kind), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,n,nb,kind,chunks,db", [(2, 200, 32, gen.U11, 1, 2), (4, 260, 32, gen.U11, 3, 2),
+                                                       (3, 150, 16, gen.INT5, 4, 3), (2, 40, 64, gen.U11, 4, 2),
+                                                       (4, 97, 16, gen.INT5, 1, 2), (2, 130, 64, gen.U11, 2, 4)])
+def test_sharded_lu_with_wider_distribution_blocks(world, n, nb, kind, chunks, db):
+    """dist_block consecutive column blocks per owner (every dist_block-th step only has a broadcast in front of the
+    next panel): same factors and pivots as the single-process twin, ragged orders and fewer groups than ranks
+    included."""
+    mp.spawn(_worker, args=(world, _free_port(), n, nb, kind, chunks, db), nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("world,n,nb,kind,chunks", [(2, 200, 32, gen.U11, 4), (4, 260, 32, gen.U11, 3),

@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nb, outdir, chunks=1):
+def _worker(rank, world, port, n, nb, outdir, chunks=1, dist_block=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,7 +38,7 @@ def _worker(rank, world, port, n, nb, outdir, chunks=1):
             dist.broadcast(h, src=src)
             t.copy_(h)
 
-        slu = ShardedLU(dev, n, nb, rank, world, bcast=bcast_via_host, chunks=chunks)
+        slu = ShardedLU(dev, n, nb, rank, world, bcast=bcast_via_host, chunks=chunks, dist_block=dist_block)
         A = slu.fill(gen.U11, 33)
         ipiv, info = slu.factor_(A)
         torch.cuda.synchronize()
@@ -54,9 +54,10 @@ def _worker(rank, world, port, n, nb, outdir, chunks=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,nb,chunks", [(1024, 128, 1), (1000, 128, 1), (640, 64, 1), (1000, 128, 4), (1536, 128, 3)])
-def test_two_ranks_one_gpu_match_single_gpu_bit_for_bit(tmp_path, n, nb, chunks):
-    mp.spawn(_worker, args=(2, _free_port(), n, nb, str(tmp_path), chunks), nprocs=2, join=True)
+@pytest.mark.parametrize("n,nb,chunks,db", [(1024, 128, 1, 1), (1000, 128, 1, 1), (640, 64, 1, 1), (1000, 128, 4, 1), (1536, 128, 3, 1),
+                                            (1536, 128, 4, 2), (1000, 128, 1, 2), (2100, 128, 2, 3)])
+def test_two_ranks_one_gpu_match_single_gpu_bit_for_bit(tmp_path, n, nb, chunks, db):
+    mp.spawn(_worker, args=(2, _free_port(), n, nb, str(tmp_path), chunks, db), nprocs=2, join=True)
     z = np.load(tmp_path / "sharded.npz")
     import linalg_solver_amd as la
     from linalg_solver_amd import dense, gen
