@@ -81,6 +81,127 @@ def cpu_baseline(sample_n: int):
     return out
 
 
+def sharded_residual(torch, dist, slu, LUloc, A0loc, piv, rehearsal):
+    """max |L U x - P A x| / (||A||_inf max|x|) of a column-sharded factorisation, x a fixed vector: every rank
+    multiplies its own column blocks, three all-reduces of n-vectors put the pieces together (a wrong trailing
+    update or a chunk-ordering bug shows here; info / |l| <= 1 / interchange range alone would pass it)."""
+    n, nb = slu.n, slu.nb
+    dev = LUloc.device
+    x = torch.cos(torch.arange(n, dtype=torch.float64, device=dev) * 0.37) + 0.25
+    rows = torch.arange(n, device=dev).unsqueeze(1)
+
+    def allsum(v):
+        if rehearsal:
+            h = v.cpu(); dist.all_reduce(h); return h.to(dev)
+        dist.all_reduce(v)
+        return v
+
+    y = torch.zeros(n, dtype=torch.float64, device=dev)
+    ax = torch.zeros(n, dtype=torch.float64, device=dev)
+    rowsum = torch.zeros(n, dtype=torch.float64, device=dev)
+    for b in slu.my_blocks:
+        o, w = slu.offset[b], slu.widths[b]
+        cols = torch.arange(b * nb, b * nb + w, device=dev).unsqueeze(0)
+        xs = x[b * nb:b * nb + w]
+        y += (LUloc[:, o:o + w].double() * (rows <= cols)) @ xs
+        ax += A0loc[:, o:o + w].double() @ xs
+        rowsum += A0loc[:, o:o + w].double().abs().sum(dim=1)
+    y, ax, rowsum = allsum(y), allsum(ax), allsum(rowsum)
+    z = torch.zeros(n, dtype=torch.float64, device=dev)
+    for b in slu.my_blocks:
+        o, w = slu.offset[b], slu.widths[b]
+        cols = torch.arange(b * nb, b * nb + w, device=dev).unsqueeze(0)
+        z += (LUloc[:, o:o + w].double() * (rows > cols)) @ y[b * nb:b * nb + w]
+    z = allsum(z) + y
+    pax = ax.cpu().numpy().copy()
+    pv = piv.cpu().numpy()
+    for k in range(n):   # the interchanges in order (LAPACK convention)
+        p_ = int(pv[k])
+        if p_ != k:
+            pax[k], pax[p_] = pax[p_], pax[k]
+    err = float((z.cpu() - torch.from_numpy(pax)).abs().max())
+    return err / (float(rowsum.max()) * float(x.abs().max()))
+
+
+def bench_mg(args, torch):
+    """--mg: ONE process, N handles on N devices, one C call per factorisation (lsx_getrf_mg_f64: the panel goes to
+    every peer with hipMemcpyPeerAsync in row chunks).  LSX_BENCH_REHEARSAL=1: all handles on GPU 0."""
+    import numpy as np
+
+    from linalg_solver_amd import gen
+    from linalg_solver_amd.device import DeviceSolver
+    from linalg_solver_amd.dist import MultiDeviceLU
+
+    P = args.gpus
+    rehearsal = os.environ.get("LSX_BENCH_REHEARSAL") == "1"
+    ndev = torch.cuda.device_count()
+    if not rehearsal and ndev < P:
+        raise SystemExit(f"--mg --gpus {P}: only {ndev} devices visible (LSX_BENCH_REHEARSAL=1 puts every handle on GPU 0)")
+    devices = [0] * P if rehearsal else list(range(P))
+    nb = args.nb or 128
+    n = args.n or int(round(8192 * (P ** (1.0 / 3.0)) / 256.0)) * 256
+    mg = MultiDeviceLU(n, devices, nb)
+    fillers = {d: DeviceSolver(d) for d in sorted(set(devices))}
+    total = args.steps + args.warmup
+
+    def make(seed):
+        locs = []
+        for d in range(P):
+            with torch.cuda.device(devices[d]):
+                loc = torch.empty(n, mg.local_cols[d], dtype=torch.float64, device=f"cuda:{devices[d]}")
+                off = 0
+                for b in mg.blocks[d]:
+                    w = min(nb, n - b * nb)
+                    fillers[devices[d]].fill_(loc[:, off:off + w], gen.U11, seed, 0, b * nb)
+                    off += w
+            locs.append(loc)
+        return locs
+
+    mats = [make(1 + s) for s in range(total)]
+
+    def sync():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    sync()
+    res = None
+    for i in range(args.warmup):
+        res = mg.factor_(mats[i])
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = mg.factor_(mats[args.warmup + i])
+    sync()
+    dt = time.perf_counter() - t0
+    ipiv, info = res
+    # in-run check of the last factorisation: info, |l| <= 1, the pivot vectors of all devices agree
+    LU = mats[args.warmup + args.steps - 1] if args.steps else mats[args.warmup - 1]
+    worst, infos = 0.0, []
+    for d in range(P):
+        off = 0
+        rows = torch.arange(n, device=LU[d].device).unsqueeze(1)
+        for b in mg.blocks[d]:
+            w = min(nb, n - b * nb)
+            cols = torch.arange(b * nb, b * nb + w, device=LU[d].device).unsqueeze(0)
+            worst = max(worst, float((LU[d][:, off:off + w].abs() * (rows > cols)).max()))
+            off += w
+        infos.append(int(info[d].item()))
+    same_piv = all(bool(torch.equal(ipiv[0].cpu(), ipiv[d].cpu())) for d in range(1, P))
+    ms = dt / max(args.steps, 1) * 1e3
+    out = {"metric": "fp64_lu_gflops", "value": lu_flops(n) * args.steps / dt / 1e9, "unit": "GFLOP/s", "n_gpus": P,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{n}x{n} f64 LU with partial pivoting, single-call multi-device driver (lsx_getrf_mg_f64)",
+                      "n": n, "nb": nb, "parallelism": f"1-D block-cyclic columns x{P}, panel written to every peer "
+                                                       f"(hipMemcpyPeerAsync, 4 row chunks), one process",
+                      "devices": devices, "devices_visible": ndev, "rehearsal_all_handles_on_gpu0": rehearsal},
+           "check": {"info": infos, "max_abs_multiplier": worst, "pivot_vectors_agree": same_piv,
+                     "ok": bool(all(v == 0 for v in infos) and worst <= 1.0 + 1e-12 and same_piv)},
+           "roofline": None, "cpu_baseline": None}
+    print(json.dumps(out))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,15 +214,43 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip solve-latency / 4096 side measurements")
+    ap.add_argument("--mg", action="store_true",
+                    help="ONE process driving --gpus N devices through lsx_getrf_mg_f64 (peer copies, no torch.distributed)")
     args = ap.parse_args()
-
-    import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if args.gpus > 1 and not args.mg and world != args.gpus:
+        if "WORLD_SIZE" in os.environ:
+            raise SystemExit(f"--gpus {args.gpus} under a launcher with WORLD_SIZE={world}")
+        # Started bare with --gpus N: become the launcher.  The ranks are CHILD processes started before this
+        # process has made any GPU call (a process that has initialised the GPU must never exec another program);
+        # rank 0's JSON line is relayed, the exit code is the launcher's.
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        line = None
+        for ln in proc.stdout.splitlines():
+            if ln.startswith("{") and '"metric"' in ln:
+                line = ln
+            else:
+                print(ln, file=sys.stderr)
+        if line:
+            print(line)
+        raise SystemExit(proc.returncode if proc.returncode else (0 if line else 1))
+
+    import torch
+
+    if args.mg:
+        return bench_mg(args, torch)
     # Rehearsal switch for a one-GPU box (not used by the driver): LSX_BENCH_REHEARSAL=1 runs every
     # rank on GPU 0 over gloo with the panel broadcast staged through the host.
     rehearsal = os.environ.get("LSX_BENCH_REHEARSAL") == "1"
@@ -116,6 +265,11 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    comm = None
+    if dist is not None:
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "devices_visible": torch.cuda.device_count(), "rehearsal_all_ranks_on_gpu0": rehearsal}
 
     from linalg_solver_amd import gen
     from linalg_solver_amd.device import DeviceSolver
@@ -239,9 +393,14 @@ def main():
             hv = vec.cpu(); dist.all_reduce(hv, op=dist.ReduceOp.MAX); vec = hv
         else:
             dist.all_reduce(vec, op=dist.ReduceOp.MAX)
+        A0 = slu.fill(gen.U11, 1 + last["i"])   # the same matrix again: the factorisation overwrote its shards
+        resid = sharded_residual(torch, dist, slu, Ash, A0, piv, rehearsal)
+        del A0
         shard_check = {"info": int(vec[2].item()), "max_abs_multiplier": float(vec[0].item()),
                         "interchanges_out_of_range": int(vec[1].item()),
-                        "ok": bool(vec[2].item() == 0 and vec[1].item() == 0 and vec[0].item() <= 1.0 + 1e-12)}
+                        "scaled_residual_LUx_minus_PAx": resid, "bound": 1e-11,
+                        "ok": bool(vec[2].item() == 0 and vec[1].item() == 0 and vec[0].item() <= 1.0 + 1e-12
+                                   and resid < 1e-11)}
 
     if rank != 0:
         if dist is not None:
@@ -340,6 +499,7 @@ def main():
         out["roofline_update"] = None
     if world > 1:
         out["check"] = shard_check
+        out["config"]["comm"] = comm
     gs = phases["gemm"]
     if world == 1 and gs["ms"] > 0:
         seq_tf = gs["flops"] / (gs["ms"] * 1e-3) / 1e12

@@ -366,9 +366,10 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         ~Restore() {
             h->stream = keep; h->panel_area_stride = 0; h->panel_area = 0; h->moves = h->moves_buf[0];
             h->gemm_queue = 0; h->gemm_counters = nullptr; h->gemm_avoid_word = nullptr; h->gemm_pass_word = nullptr;
-            h->gemm_col0 = nullptr; h->panel_xcc_word = nullptr;
+            h->gemm_col0 = nullptr; h->panel_xcc_word = nullptr; h->chain_info = nullptr;
         }
     } restore{h, main_s};
+    h->chain_info = d_info;
     JoinSide join{h, side, main_s, main_s};
     // three exchange areas in rotation (panel j uses area j % 3, cleared behind update j), then the words
     char *wbase = (char *)h->scratch + 3 * area;
@@ -754,6 +755,9 @@ static int factor_from_host(lsx_handle_t h, int n, const T *A, int lda, T *dA, i
         LSX_HIP(hipMemcpyAsync(hinfo, dinfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
         LSX_HIP(hipStreamSynchronize(h->stream));
         if (*hinfo >= 0) return LSX_OK;
+        // the time-out also set the status word; this call reports (or repairs) it, so it must not be left for the
+        // next, unrelated call on the handle to find
+        LSX_HIP(hipMemsetAsync(h->dev_status, 0, 3 * sizeof(int), h->stream));
     }
     set_error("panel exchange timed out on the device, and so did the per-column fallback");
     return LSX_ERR_INTERNAL;
@@ -1039,6 +1043,12 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_xcd")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_xcd = value;
+    } else if (!strcmp(key, "chain_wait_limit")) {   // tests: 0 makes the chain's wait for the update's first tile column a time-out
+        LSX_ARG(value >= 0);
+        h->chain_wait_limit = value;
+    } else if (!strcmp(key, "panel_proto")) {
+        LSX_ARG(value == 0 || value == 1);
+        h->panel_proto = value;
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
@@ -1068,6 +1078,8 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "trsv")) *value = h->trsv_mode;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
+    else if (!strcmp(key, "panel_proto")) *value = h->panel_proto;
+    else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "diag_panels")) {
 #ifdef LSX_DIAG_PANELS

@@ -104,6 +104,8 @@ struct lsx_handle_s {
     int *gemm_counters = nullptr; // gemm_counter_sets x 8 ints in scratch, zeroed by the driver
     int gemm_counter_sets = 0, gemm_counter_set = 0;
     int *gemm_pass_word = nullptr;   // incremented by every workgroup that leaves because it sits on the avoided XCD
+    int *chain_info = nullptr;       // look-ahead driver: the factorisation's info word, for the chain's in-kernel waits (time-out -> negative)
+    int chain_wait_limit = 1 << 21;  // polls of those waits before they give up (option chain_wait_limit: tests inject a time-out with 0)
     int *gemm_col0 = nullptr;        // look-ahead driver: {ticket, done} words of this update's tile column 0 (zeroed by the driver)
     int gemm_col0_tiles = 0;         // set with it: tiles in that column
     int x_events = 0;                // option x_events (measurements, tests): no column-0 ordering in the XCD-scope schedule
@@ -111,6 +113,7 @@ struct lsx_handle_s {
     int gemm_queue_used = 0;         // set by the last launch_gemm_*: 1 = its interior went through the queue
     void *moves_all = nullptr;       // look-ahead driver with the XCD-scope panel: one gather list per panel
     size_t moves_all_bytes = 0;
+    int panel_proto = 1;  // XCD-scope panel: 0 = first protocol (kernels_panel_x.hip), 1 = whole-record poll (kernels_panel_y.hip)
     int panel_xcd = 0;    // 1: pipelined panel with the exchange at XCD scope (<= 32 workgroups on one XCD)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     // set by the LU drivers: updates narrower than 16 columns also take the MFMA kernel, so that a column sees the

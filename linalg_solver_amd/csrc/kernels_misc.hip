@@ -270,7 +270,9 @@ int launch_gate(lsx_handle_t h, const int *word, int target) {
 // One wave that waits until *word >= target and, unlike the gate, must not give up quietly: the look-ahead driver
 // orders the panel chain behind the update's tile column 0 with it (gemm_sub_queue_kernel counts that column's
 // finished tiles), in place of an event behind the whole update.  A time-out (~seconds) is recorded in `status`.
-__global__ __launch_bounds__(64) void wait_count_kernel(const int *word, int target, int limit, int *status) {
+// and, as for a panel whose exchange timed out, as a negative value in the factorisation's info word: whatever is
+// computed behind a time-out works on stale columns, and info < 0 is what every caller already checks.
+__global__ __launch_bounds__(64) void wait_count_kernel(const int *word, int target, int limit, int *status, int *info) {
     LSX_TS(7);
     if (threadIdx.x == 0) {
         for (int i = 0; i < limit; ++i) {
@@ -278,10 +280,12 @@ __global__ __launch_bounds__(64) void wait_count_kernel(const int *word, int tar
             __builtin_amdgcn_s_sleep(4);
         }
         if (status) atomicMax(status, 1);
+        if (info) atomicMin(info, -0x40000000);
     }
 }
 int launch_wait_count(lsx_handle_t h, const int *word, int target) {
-    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, h->stream, word, target, 1 << 21, h->dev_status);
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(64), 0, h->stream, word, target, h->chain_wait_limit, h->dev_status,
+                       h->chain_info);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -455,16 +459,19 @@ template <typename T, int CW, int VW>
 __global__ __launch_bounds__(256) void chain_head_kernel(int ntri, int jb, const T *__restrict__ Tm, int ldt,
                                                          T *__restrict__ Tinv, int ncols, T *__restrict__ A, int lda,
                                                          int row0, const int2 *__restrict__ moves,
-                                                         const int *wait_word, int wait_target, int *status) {
+                                                         const int *wait_word, int wait_target, int wait_limit,
+                                                         int *status, int *info) {
     LSX_TS(2);
     if (wait_word) {
         if (threadIdx.x == 0) {
             bool ok = false;
-            for (int i = 0; i < (1 << 21) && !ok; ++i) {
+            for (int i = 0; i < wait_limit && !ok; ++i) {
                 ok = __hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_target;
                 if (!ok) __builtin_amdgcn_s_sleep(2);
             }
+            // a time-out must reach the caller like a panel's: the columns behind it are stale (info < 0)
             if (!ok && status) atomicMax(status, 1);
+            if (!ok && info && blockIdx.x == 0) atomicMin(info, -0x40000000);
             __atomic_thread_fence(__ATOMIC_ACQUIRE);   // device scope: the counted tiles' stores are visible from here on
         }
         __syncthreads();
@@ -487,7 +494,7 @@ int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int
     ProfScope ps(h, LSX_PROF_TRSM);
     hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
                        ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)h->moves, wait_word, wait_target,
-                       h->dev_status);
+                       h->chain_wait_limit, h->dev_status, h->chain_info);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -503,7 +510,7 @@ int diag_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int n
     const int ntri = (jb + TB - 1) / TB;
     hipLaunchKernelGGL((chain_head_kernel<T, CW, VW>), dim3(ntri + (ncols / VW + CW - 1) / CW), dim3(256), 0, h->stream,
                        ntri, jb, Tm, ldt, Tinv, ncols / VW, A, lda / VW, row0, (const int2 *)moves, (const int *)nullptr, 0,
-                       (int *)nullptr);
+                       0, (int *)nullptr, (int *)nullptr);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }

@@ -1045,6 +1045,44 @@ def test_panel_exchange_timeout_falls_back_to_per_column_launches(la):
     assert info2 == 0 and np.array_equal(LU2, ref[0]) and h.get_option("panel_fallbacks") == before + 2
 
 
+def test_chain_wait_timeout_reaches_info_and_the_host_entry_point_recovers(la, dev):
+    """the look-ahead chain waits INSIDE a kernel for the previous update's first tile column (bounded
+    spin).  A time-out there used to set only the status word and go on with stale columns: the device entry point
+    must leave info < 0, lsx_check_status must report it once (and clear it), and the host-buffer entry point must
+    hand back right factors through its per-column fallback -- not LSX_OK with garbage.  Fault injection: a wait
+    limit of 0 polls."""
+    import torch
+
+    from linalg_solver_amd import _native, dense, gen
+
+    h = la.default_handle()
+    n = 2560   # look-ahead driver with the counted wait (n >= 2048, no ragged edge)
+    A, b = gen.system(gen.U11, 21, n)
+    ref = dense.lu_factor(A)
+    before = h.get_option("panel_fallbacks")
+    try:
+        h.set_option("chain_wait_limit", 0)
+        dev.h.set_option("chain_wait_limit", 0)
+        LU, ipiv, info = dense.lu_factor(A)            # host buffers: falls back, right result
+        dA = torch.from_numpy(A).cuda()
+        dp, dinfo = dev.getrf_(dA)                     # device pointers: info < 0, nothing hidden
+        torch.cuda.synchronize()
+    finally:
+        h.set_option("chain_wait_limit", 1 << 21)
+        dev.h.set_option("chain_wait_limit", 1 << 21)
+    assert info == 0 and np.array_equal(ipiv, ref[1]) and np.array_equal(LU, ref[0])
+    assert h.get_option("panel_fallbacks") == before + 1
+    h.check_status()                                   # the host entry point left no stale status word behind
+    assert int(dinfo.item()) < 0
+    with pytest.raises(_native.LsxError):
+        dev.h.check_status()
+    dev.h.check_status()                               # reported once, then clean
+    dA = torch.from_numpy(A).cuda()
+    dp, dinfo = dev.getrf_(dA)
+    torch.cuda.synchronize()
+    assert int(dinfo.item()) == 0 and np.array_equal(dA.cpu().numpy(), ref[0])
+
+
 def test_from_dlpack_of_a_device_tensor_is_a_view_not_a_copy(la):
     """VERDICT r1 housekeeping: Matrix.from_dlpack of a tensor in HBM keeps the tensor; solve_array / inverse_array
     run through the *_dev entry points and return device tensors; the host copy appears only when asked for."""
