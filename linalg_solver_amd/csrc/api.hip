@@ -646,6 +646,12 @@ static int getrs_dev(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, cons
         T *Bc = (T *)((char *)h->ws3 + pad256(sizeof(int32_t) * n));  // copy of B, zero-padded to nr columns
         T *Bp = (T *)((char *)Bc + vec);                               // P * B, work space of the solve
         T *X = (T *)((char *)Bp + vec);
+        char *w2 = (char *)h->ws2;
+        if (h->trsv_mode == 2) {   // 128-row steps, helper workgroups, interchanges + gather fused into the preparation launch
+            const int r2 = lu_solve_few_rhs2<T>(h, n, nrhs, nr, LU, lda, d_ipiv, B, ldb, (T *)w2, (T *)(w2 + b64),
+                                                (T *)(w2 + 2 * b64), (T *)(w2 + 2 * b64 + b128), Bp, X);
+            if (r2 != 1) return r2;
+        }
         LSX_TRY(launch_ipiv_to_perm(h, n, d_ipiv, perm));
         if (nr != nrhs) LSX_HIP(hipMemsetAsync(Bc, 0, sizeof(T) * (size_t)n * nr, h->stream));
         LSX_TRY(launch_copy2d<T>(h, n, nrhs, B, ldb, Bc, nr));
@@ -931,6 +937,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->ws4) (void)hipFree(h->ws4);
+    if (h->xchg) (void)hipFree(h->xchg);
     if (h->ws5) (void)hipFree(h->ws5);
     if (h->scratch) (void)hipFree(h->scratch);
     if (h->moves_buf[0]) (void)hipFree(h->moves_buf[0]);
@@ -993,7 +1000,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
 #endif
         h->panel_mode = value;
     } else if (!strcmp(key, "trsv")) {
-        LSX_ARG(value == 0 || value == 1);
+        LSX_ARG(value >= 0 && value <= 2);
         h->trsv_mode = value;
     } else if (!strcmp(key, "gemm_tiles32")) {
         LSX_ARG(value == 0 || value == 1);
@@ -1046,9 +1053,6 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "chain_wait_limit")) {   // tests: 0 makes the chain's wait for the update's first tile column a time-out
         LSX_ARG(value >= 0);
         h->chain_wait_limit = value;
-    } else if (!strcmp(key, "panel_proto")) {
-        LSX_ARG(value == 0 || value == 1);
-        h->panel_proto = value;
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
@@ -1078,7 +1082,6 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "trsv")) *value = h->trsv_mode;
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
-    else if (!strcmp(key, "panel_proto")) *value = h->panel_proto;
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "diag_panels")) {

@@ -94,7 +94,7 @@ struct lsx_handle_s {
     int lookahead_min = 0; // smallest n the look-ahead driver takes (0 = measured default: 7168 fp64, 10240 fp32)
     int panel_rt = 4;     // rows per thread in the cooperative panel
     int panel_nt = 0;     // threads per workgroup in the cooperative panel (0 = choose by panel height)
-    int trsv_mode = 1;    // few-RHS solve: 1 = one cooperative launch per direction, 0 = one launch per 128-row step
+    int trsv_mode = 2;    // few-RHS solve: 2 = 128-row steps + helper workgroups (default), 1 = one cooperative launch per direction with 64-row steps, 0 = one launch per 128-row step
     int gemm_stagger = 0; // trailing update: start delay of every second resident workgroup, units of 8128 clocks
     int gemm_waves = 0;   // waves per workgroup in the trailing-update kernel (0 = auto; 4: 64x64 per wave, 8: 64x32)
     // trailing update through a work queue (look-ahead driver with the XCD-scope panel): see kernels_gemm.hip
@@ -113,7 +113,6 @@ struct lsx_handle_s {
     int gemm_queue_used = 0;         // set by the last launch_gemm_*: 1 = its interior went through the queue
     void *moves_all = nullptr;       // look-ahead driver with the XCD-scope panel: one gather list per panel
     size_t moves_all_bytes = 0;
-    int panel_proto = 1;  // XCD-scope panel: 0 = first protocol (kernels_panel_x.hip), 1 = whole-record poll (kernels_panel_y.hip)
     int panel_xcd = 0;    // 1: pipelined panel with the exchange at XCD scope (<= 32 workgroups on one XCD)
     int panel_debug = 0;  // 1: stamped diagnostic panel kernel (tools/kbench.py)
     // set by the LU drivers: updates narrower than 16 columns also take the MFMA kernel, so that a column sees the
@@ -134,6 +133,9 @@ struct lsx_handle_s {
     void *ws5 = nullptr;     // work matrix of the structured inverse (getri)
     size_t ws5_bytes = 0;
     int getri_plain = 0;     // option getri_structured=0: the inverse as a plain n-right-hand-side solve of P*I
+    void *xchg = nullptr;    // few-RHS solve (kernels_trsv.hip, third form): exchange granules validated by an epoch, never cleared
+    size_t xchg_bytes = 0;
+    unsigned xchg_epoch = 0;
     void *ws4 = nullptr;     // residual / correction of the mixed-precision solve
     size_t ws4_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
@@ -270,6 +272,9 @@ int launch_amax(lsx_handle_t h, int m, int n, const T *A, int lda, double *d_out
 template <typename T>
 int launch_diag_minabs(lsx_handle_t h, int n, const T *LU, int lda, double *d_out);
 // X (n x nrhs, ld = nrhs) <- U^-1 L^-1 B, nrhs <= 8, one launch per 128-row block step
+template <typename T>
+int lu_solve_few_rhs2(lsx_handle_t h, int n, int nrhs, int nr, const T *LU, int lda, const int32_t *d_ipiv, T *B, int ldb,
+                      T *inv64L, T *inv64U, T *inv128L, T *inv128U, T *Bp, T *Y);
 template <typename T>
 int lu_solve_few_rhs(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *B, int ldb, T *X, T *inv64L,
                      T *inv64U, T *inv128L, T *inv128U);

@@ -167,9 +167,6 @@ template <typename T>
 int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info);
 
 template <typename T>
-int panel_ycd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info);
-
-template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
                  int *d_info) {
     if (m <= 0 || jb <= 0) return LSX_OK;
@@ -177,8 +174,7 @@ int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t
     ProfScope ps(h, LSX_PROF_PANEL, 0, 2.0 * sizeof(T) * m * (double)jb);
     // the panel's first column is global column row0 (square LU: panel starts on the diagonal)
     if (h->panel_mode == 4) {   // XCD-scope exchange; taller panels than one XCD holds take the device-scope kernel
-        const int r = h->panel_proto ? panel_ycd<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info)
-                                     : panel_xcd<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
+        const int r = panel_xcd<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
         if (r != 1) return r;
     }
     if (h->panel_mode >= 3) {

@@ -759,11 +759,12 @@ def test_full_size_fp32(dev):
     assert float(D.abs().max() / A.abs().max()) < 1e-3
 
 
-@pytest.mark.parametrize("n", [129, 200, 1000, 2500])
+@pytest.mark.parametrize("n", [129, 200, 1000, 2500, 4096, 4100])
 @pytest.mark.parametrize("nrhs", [1, 2, 3, 8])
 def test_cooperative_triangular_solve_matches_the_step_path(la, n, nrhs):
-    """Few right-hand sides: one cooperative launch per direction (option trsv=1, default) against one
-    launch per 128-row step (trsv=0) and against the CPU twin."""
+    """Few right-hand sides: the three forms of the solve-latency path -- 128-row steps with helper workgroups
+    and the interchanges fused into the preparation launch (trsv=2, default), one cooperative launch per direction
+    with 64-row steps (trsv=1), one launch per 128-row step (trsv=0) -- against each other and the CPU twin."""
     from linalg_solver_amd import dense, gen
 
     A, _ = gen.system(gen.U11, 900 + n, n)
@@ -777,12 +778,17 @@ def test_cooperative_triangular_solve_matches_the_step_path(la, n, nrhs):
         x0 = dense.lu_solve(LU, ipiv, B)
         h.set_option("trsv", 1)
         x1 = dense.lu_solve(LU, ipiv, B)
+        h.set_option("trsv", 2)
+        x2 = dense.lu_solve(LU, ipiv, B)
+        x2b = dense.lu_solve(LU, ipiv, B)
     finally:
-        h.set_option("trsv", 1)
+        h.set_option("trsv", 2)
     oLU, oipiv, _ = capi.getrf(A)
     xo = capi.getrs(oLU, oipiv, B)
     assert relerr(x1, x0) < 1e-11 and relerr(x1, xo) < TOL64
-    assert np.max(np.abs(A @ x1 - B)) < 1e-9 * n
+    assert relerr(x2, x0) < 1e-11 and relerr(x2, xo) < TOL64
+    assert np.array_equal(x2, x2b), "the solve is not deterministic"
+    assert np.max(np.abs(A @ x1 - B)) < 1e-9 * n and np.max(np.abs(A @ x2 - B)) < 1e-9 * n
 
 
 @pytest.mark.parametrize("n,nrhs", [(300, 1), (1000, 4), (2048, 1)])
@@ -799,10 +805,13 @@ def test_cooperative_triangular_solve_fp32(la, n, nrhs):
         h.set_option("trsv", 0)
         x0 = dense.lu_solve(LU, ipiv, B.astype(np.float32))
         h.set_option("trsv", 1)
+        x1o = dense.lu_solve(LU, ipiv, B.astype(np.float32))
+        h.set_option("trsv", 2)
         x1 = dense.lu_solve(LU, ipiv, B.astype(np.float32))
     finally:
-        h.set_option("trsv", 1)
+        h.set_option("trsv", 2)
     assert x1.dtype == np.float32 and relerr(x1.astype(np.float64), x0.astype(np.float64)) < 1e-4
+    assert relerr(x1o.astype(np.float64), x0.astype(np.float64)) < 1e-4
     # norm-wise backward error of the fp32 solve
     resid = np.linalg.norm(A @ x1.astype(np.float64) - B) / (np.linalg.norm(A) * np.linalg.norm(x1) + np.linalg.norm(B))
     assert resid < 1e-4
@@ -981,10 +990,13 @@ def test_cooperative_solve_timeout_is_an_error_not_a_result(la):
     assert info == 0
     try:
         h.set_option("trsv_spin_limit", 0)
-        with pytest.raises(_native.LsxError):
-            dense.lu_solve(LU, ipiv, b)
+        for mode in (2, 1):
+            h.set_option("trsv", mode)
+            with pytest.raises(_native.LsxError):
+                dense.lu_solve(LU, ipiv, b)
     finally:
         h.set_option("trsv_spin_limit", 1 << 20)
+        h.set_option("trsv", 2)
     h.check_status()   # the word was cleared with the error
     x = dense.lu_solve(LU, ipiv, b)
     assert np.max(np.abs(A @ x - b)) / (np.max(np.abs(A)) * np.max(np.abs(x)) * n) < 1e-14

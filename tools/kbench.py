@@ -199,7 +199,7 @@ def main():
     if "panelx" in args.what or "pstamps" in args.what:
         import numpy as np
         # device-scope pipelined panel (panel=3) / the same with XCD-scope stores (panel_xcd=1) / XCD kernel (panel=4)
-        variants = (("p3", 3, 0, 0), ("p4", 4, 0, 0), ("p4y", 4, 0, 1))
+        variants = (("p3", 3, 0), ("p3x", 3, 1), ("p4", 4, 0))
         dev.h.set_option("panel_nt", 0)
         dev.h.set_option("panel_rt", 4)
         dt = torch.float32 if args.f32 else torch.float64
@@ -209,10 +209,9 @@ def main():
                     P0 = torch.empty(m, nbw, dtype=dt, device="cuda")
                     dev.fill_(P0, kind, 3)
                     outs = []
-                    for nm, mode, xcd, proto in variants:
+                    for nm, mode, xcd in variants:
                         dev.h.set_option("panel", mode)
                         dev.h.set_option("panel_xcd", xcd)
-                        dev.h.set_option("panel_proto", proto)
                         P = P0.clone()
                         ipiv = torch.zeros(nbw, dtype=torch.int32, device="cuda")
                         info = torch.zeros(1, dtype=torch.int32, device="cuda")
@@ -224,10 +223,9 @@ def main():
                         same = torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]) and outs[0][2] == outs[k][2]
                         res.append(f"{variants[k][0]}={'same' if same else 'MISMATCH'}(info {outs[k][2]})")
                     print(f"panelx check m={m} jb={nbw} kind={kind}: " + " ".join(res), flush=True)
-        for nm, mode, xcd, proto in variants if "panelx" in args.what else ():
+        for nm, mode, xcd in variants if "panelx" in args.what else ():
             dev.h.set_option("panel", mode)
             dev.h.set_option("panel_xcd", xcd)
-            dev.h.set_option("panel_proto", proto)
             for m in (8192, 6144, 4096, 2048, 1024, 256):
                 P0 = torch.empty(m, args.nb, dtype=dt, device="cuda")
                 dev.fill_(P0, gen.U11, 3)
@@ -242,11 +240,10 @@ def main():
                 tcopy, _ = timeit(lambda: P.copy_(P0), reps=7, warm=2)
                 t = tmin - tcopy
                 print(f"panel {nm} m={m} nb={args.nb}: {t * 1e3:.1f} us  ({t * 1e3 / args.nb:.2f} us/col)", flush=True)
-        names = ["own: step start -> records valid", "own: arg-max, 1/pivot, multipliers, block update", "own: choose + record", "own: LDS (multipliers, info), poll issue",
-                 "next wave: barrier wait", "next wave: far granules+update", "next wave: publish", "own: barrier"]
+        names = ["own: headers+winner", "own: multipliers+granules", "own: update+choose+announce", "own: barrier",
+                 "next wave: barrier wait", "next wave: far granules+update", "next wave: publish", "own: second block behind the barrier"]
         dev.h.set_option("panel", 4)
         dev.h.set_option("panel_xcd", 0)
-        dev.h.set_option("panel_proto", 1)
         dev.h.set_option("panel_debug", 1)
         for m in (8192, 4096, 2048, 256):
             rows = 64 * (1 if m <= 2048 else 2 if m <= 4096 else 4 if (m <= 8192 or not args.f32) else 8)
@@ -263,7 +260,7 @@ def main():
             raw = np.frombuffer(dev.h.read_scratch(off, G * 128), dtype=np.uint64).reshape(G, 16)
             us = raw.astype(np.float64) / 100.0 / args.nb
             tag = f" xcc ids {sorted(set((raw[:, 15] >> 8).tolist()))} same-flag {sorted(set((raw[:, 15] & 1).tolist()))}"
-            print(f"stamps4 m={m} G={G}: us per column (mean | max over workgroups)   owner total {us[:, [0, 1, 2, 3, 7]].sum(1).mean():.2f}  re-polls per column {raw[:, 8].mean() / args.nb:.2f}{tag}")
+            print(f"stamps4 m={m} G={G}: us per column (mean | max over workgroups)   owner total {us[:, [0, 1, 2, 3, 7]].sum(1).mean():.2f}{tag}")
             for i, nm in enumerate(names[:8]):
                 print(f"   {nm:30s} {us[:, i].mean():7.3f} | {us[:, i].max():7.3f}")
         dev.h.set_option("panel_debug", 0)

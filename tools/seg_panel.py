@@ -7,9 +7,9 @@ import numpy as np, torch
 from linalg_solver_amd import gen
 from linalg_solver_amd.device import DeviceSolver
 
-names = ["0 step start -> all records valid", "1 header arg-max + readlanes", "2 1/pivot, multipliers",
-         "3 update of the block (readlanes + FMAs)", "4 choose + arg-max + record (LDS staging, store)", "5 multipliers + s_info to LDS, status",
-         "6 poll issue", "7 barrier"]
+names = ["0 step start -> shot A landed", "1 absorb + header arg-max + readlanes", "2 near load issue, 1/pivot, multipliers, LDS",
+         "3 wait: shot B + near granules", "4 update of the block", "5 choose + arg-max + announce (header, near)",
+         "6 s_info, shot A", "7 barrier (+ shot B)"]
 k = int(os.environ.get("LSX_LIB_OVERRIDE", "seg-1").split("seg")[-1].split(".")[0])
 dev = DeviceSolver()
 dev.h.set_option("panel", 4)
@@ -26,5 +26,5 @@ for m in (8192, 256):
     need = 256 + 2 * G * 128 + 4 * G * 128 * 16
     off = (need + 255) & ~255
     raw = np.frombuffer(dev.h.read_scratch(off, G * 128), dtype=np.uint64).reshape(G, 16)
-    cyc = raw[:, 12].astype(np.float64) / 128.0   # 128 owner steps per panel
+    cyc = raw[:, 12].astype(np.float64) / 112.0   # 112 owner steps with a successor in the same block per panel (7 of 8 columns)
     print(f"seg {names[k]:52s} m={m:5d}: {cyc.mean():7.0f} cycles per column (max {cyc.max():7.0f})", flush=True)
