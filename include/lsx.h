@@ -78,13 +78,23 @@ int lsx_use_own_stream(lsx_handle_t h);
 int lsx_synchronize(lsx_handle_t h);
 /* Thread-local text of the last failure on this thread ("" if none). */
 const char *lsx_last_error(void);
-/* Tunables: "nb" (panel width <= 128), "panel" (0 = per-column launches, 1 = cooperative,
- * 2 = blocked cooperative, 3 = pipelined cooperative [default]), "lookahead" (0 = sequential, 1 = next panel on a side stream under
- * the trailing update for n >= 7168 (fp32: 10240) [default], 2 = the same on disjoint CU sets, 3 = 1; all
- * bit-identical), "lookahead_min" (smallest n that takes the look-ahead driver;
- * 0 = the measured break-even), "kblock" (panels per trailing update),
- * "gemm_waves", "gemm_stagger", "panel_rt", "panel_nt", "trsv" (few-RHS solve: 1 = one cooperative launch
- * per direction [default], 0 = one launch per 128-row step).  Returns LSX_ERR_ARG for unknown keys. */
+/* Tunables (defaults in brackets; every variant gives bit-identical factors):
+ *   "nb"            panel width, <= 128 [128]
+ *   "panel"         0 = per-column launches (the fallback after an exchange time-out), 3 = one launch per panel,
+ *                   device-scope pivot exchange (panels taller than one XCD holds, multi-device driver),
+ *                   4 = one launch per panel on ONE XCD with the exchange in that XCD's L2 [4]
+ *                   (1, 2: superseded kernels, only in `make DIAG=1` builds)
+ *   "lookahead"     0 = sequential driver, 1 = the next panel is factored on a side stream under the trailing
+ *                   update [1]
+ *   "lookahead_min" smallest n that takes the look-ahead driver; 0 = the measured break-even: 2048 in fp64 and
+ *                   4096 in fp32 with panel = 4 (7168 / 10240 with panel = 3) [0]
+ *   "kblock"        panels per trailing update [1]
+ *   "trsv"          few-right-hand-side solve: 2 = 128-row steps with helper workgroups, one preparation launch [2],
+ *                   1 = one cooperative launch per direction with 64-row steps, 0 = one launch per 128-row step
+ *   "gemm_waves", "gemm_stagger", "panel_rt", "panel_nt", "hybrid", "xrows_limit", "rref_blocked",
+ *   "getri_structured"                      tuning / cross-check switches, see DESIGN.md
+ *   "panel_spin_limit", "trsv_spin_limit", "chain_wait_limit"   bounded-spin limits (tests inject time-outs)
+ * Returns LSX_ERR_ARG for unknown keys or values. */
 int lsx_set_option(lsx_handle_t h, const char *key, int value);
 /* The cooperative kernels (panel pivot exchange, few-right-hand-side solve) poll each other with a bounded spin; a
  * time-out -- their workgroups were not all resident, e.g. another kernel held the CUs -- is recorded in a device

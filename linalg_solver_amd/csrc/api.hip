@@ -133,28 +133,9 @@ static int apply_panel_swaps(lsx_handle_t h, int ncols, T *Acols, int lda, int r
 // (P(k) is recorded behind the next panel's column block when both streams share the CUs.)
 // Disjointness: the side stream's step k touches columns [k+jb, k+2jb); the main stream's step k writes
 // columns >= k+2jb and < k and reads L21 (columns [k,k+jb)), U12 (rows [k,k+jb)) and the block inverses.
-// Two streams masked to disjoint CU sets: `panel_cus` CUs for the panel, the rest for the update.
-static int ensure_partition(lsx_handle_t h, int panel_cus) {
-    if (h->part_panel_cus == panel_cus && h->part_update && h->part_panel) return LSX_OK;
-    if (h->part_update) { (void)hipStreamDestroy(h->part_update); h->part_update = nullptr; }
-    if (h->part_panel) { (void)hipStreamDestroy(h->part_panel); h->part_panel = nullptr; }
-    h->part_panel_cus = 0;
-    const int ncu = h->num_cu;
-    std::vector<uint32_t> mp((ncu + 31) / 32, 0u), mu((ncu + 31) / 32, 0u);
-    // contiguous ranges: the top `panel_cus` mask bits for the panel, the rest for the update
-    // (an every-other-CU pattern was silently ignored by the dispatcher on this stack)
-    int given = 0;
-    for (int cu = 0; cu < ncu; ++cu) {
-        if (cu >= ncu - panel_cus) { mp[cu / 32] |= 1u << (cu % 32); ++given; }
-        else mu[cu / 32] |= 1u << (cu % 32);
-    }
-    if (given < panel_cus) { set_error("CU partition: cannot give %d CUs to the panel", panel_cus); return LSX_ERR_ARG; }
-    LSX_HIP(hipExtStreamCreateWithCUMask(&h->part_update, (uint32_t)mu.size(), mu.data()));
-    LSX_HIP(hipExtStreamCreateWithCUMask(&h->part_panel, (uint32_t)mp.size(), mp.data()));
-    h->part_panel_cus = panel_cus;
-    return LSX_OK;
-}
-
+// (A third variant confined the two streams to disjoint CU sets with hipExtStreamCreateWithCUMask.  A CU mask thins
+// out the CUs of EVERY XCD alike and cannot keep a kernel off an XCD, so it never separated the kernels and was
+// level with this one at best: removed in round 3, history in DESIGN 6.2.)
 // On an error return inside a two-stream driver, work already queued on the side stream must not outlive the
 // call: the caller's stream waits for it (the next call on the handle, or the caller reading A, would race otherwise).
 struct JoinSide {
@@ -172,7 +153,7 @@ struct JoinSide {
 // the XCD-scope driver takes over from there.
 template <typename T>
 static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info, T *Tinv,
-                           int k0, bool want_partition, int k_stop = 0) {
+                           int k0, int k_stop = 0) {
     const int nb = h->nb;
     struct OnSide {  // launches inside this scope go to the given stream
         lsx_handle_t h; hipStream_t keep;
@@ -181,27 +162,6 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     };
     hipStream_t caller = h->stream;
     hipStream_t main_s = h->stream, side = h->side_stream;
-    bool partitioned = want_partition;
-    int slice_rt = 4;
-    if (partitioned) {
-        // the panel's workgroups (128 rows each) all need a CU of their own inside the panel's CU
-        // set; one and a half times as many CUs as workgroups are reserved, in multiples of 32
-        slice_rt = (n - k0 > 8192) ? 8 : 4;             // 256-row slices above 8192 rows: half the workgroups
-        const int G = (n - k0 + 32 * slice_rt - 1) / (32 * slice_rt);
-        int pcus = ((G + G / 2 + 31) / 32) * 32;
-        if (pcus > h->num_cu / 2) pcus = h->num_cu / 2;
-        if (const char *e = getenv("LSX_PANEL_CUS")) {   // diagnostics: force the split (kept inside the chip)
-            const int v = atoi(e);
-            if (v >= 1 && v <= h->num_cu / 2) pcus = v;
-        }
-        if (pcus < G) {
-            partitioned = false;   // the panel does not fit in half the chip: plain look-ahead
-        } else {
-            LSX_TRY(ensure_partition(h, pcus));
-            main_s = h->part_update;
-            side = h->part_panel;
-        }
-    }
     struct Restore {  // the handle's stream is the update stream while this driver runs
         lsx_handle_t h; hipStream_t keep; int nt, rt, mode;
         ~Restore() { h->stream = keep; h->panel_nt = nt; h->panel_rt = rt; h->panel_mode = mode; h->panel_area_stride = 0; h->panel_area = 0; }
@@ -210,14 +170,6 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     // this schedule shares the CUs between the panel and the update: the XCD-scope panel (which fills an XCD) has
     // its own driver, getrf_lookahead_x; here it would stall every launch beside it
     if (h->panel_mode == 4) h->panel_mode = 3;
-    if (partitioned) {
-        // every panel workgroup must be resident inside the panel's CU set: 128-row slices only
-        h->panel_nt = 512;
-        h->panel_rt = slice_rt;
-        LSX_HIP(hipEventRecord(h->ev_start, caller));
-        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_start, 0));
-        h->stream = main_s;
-    }
     // Exchange areas of the pipelined panel: two, used alternately, and cleared HERE on the main stream as
     // soon as their panel has finished -- a clear in front of every panel launch sits on the chain.
     size_t area = panel_pipe_area_bytes(h, n - k0);
@@ -281,28 +233,20 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         {
             OnSide g(h, side);
             h->moves = h->moves_buf[step & 1];
-            // block inverses and the next block's interchanges in one launch when the main stream does not
-            // need the inverses earlier (it starts behind the chain anyway when the CUs are shared)
-            int fused = 1;
-            if (!partitioned) {
-                if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
-                fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
-                if (fused < 0) return fused;
-            }
+            // block inverses and the next block's interchanges in one launch (the main stream starts behind the
+            // chain anyway: the CUs are shared)
+            if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
+            if (fused < 0) return fused;
             if (fused == 1) {
                 LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
-                if (partitioned) {
-                    LSX_HIP(hipEventRecord(h->ev_panel, side));   // panel k and its block inverses are done
-                    if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
-                }
                 LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
             }
             LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
             LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
             // Sharing the CUs, the big update would take the slots these small launches need (measured:
-            // the chain doubles); the main stream then starts behind the chain.  On disjoint CU sets it
-            // starts as soon as panel k and its block inverses are there.
-            if (!partitioned) LSX_HIP(hipEventRecord(h->ev_panel, side));
+            // the chain doubles); the main stream therefore starts behind the chain.
+            LSX_HIP(hipEventRecord(h->ev_panel, side));
             h->moves = h->moves_buf[(step + 1) & 1];
             h->panel_area = (step + 1) & 1;
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
@@ -327,10 +271,6 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         h->moves_valid = next_valid;
     }
     join.armed = false;   // both streams were joined by the last step
-    if (partitioned) {  // hand the result back to the caller's stream
-        LSX_HIP(hipEventRecord(h->ev_done, main_s));
-        LSX_HIP(hipStreamWaitEvent(caller, h->ev_done, 0));
-    }
     return LSX_OK;
 }
 
@@ -524,11 +464,6 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     }
     int k_end = n;  // the sequential driver below handles columns [0, k_end)
     if (h->lookahead && n >= LOOKAHEAD_MIN && h->kblock == 1) k_end = 0;
-    // lookahead = 1 / 3: both streams on all CUs; 2: on disjoint CU sets.  For ONE fp32 factorisation the
-    // partition is the faster variant between 7168 and ~14000 (8192: 20.8 ms against 22.4 sequential and 22.4
-    // shared), but factorisations issued back to back lose that again (23.6 against 22.6 ms per LU: measured,
-    // not yet explained), so the default stays with the shared-CU variant and its break-even.
-    const bool want_partition = h->lookahead == 2;
     const int W = nb * h->kblock;
     for (int k = 0; k < k_end; k += W) {
         const int w = (n - k < W) ? n - k : W;  // width of this super-block
@@ -583,17 +518,17 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
         // device-scope panel (12288^2 fp64: 46.4 -> see DESIGN 6).
         int xrows = 32 * 64 * (sizeof(T) == 8 ? 4 : 8);
         if (h->xrows_limit > 0 && h->xrows_limit < xrows) xrows = h->xrows_limit;   // tests: hand-over at small orders
-        if (h->panel_mode == 4 && !want_partition && !h->panel_debug && nb % 32 == 0 && k_end % 32 == 0 &&
+        if (h->panel_mode == 4 && !h->panel_debug && nb % 32 == 0 && k_end % 32 == 0 &&
             panel_x_area_bytes(h, n - k_end, sizeof(T)) > 0) {
             int kx = k_end;
             if (n - kx > xrows) kx += (n - kx - xrows + nb - 1) / nb * nb;
             if (h->hybrid_off && kx > k_end) kx = n;
             if (kx < n) {
-                if (kx > k_end) LSX_TRY(getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, false, kx));
+                if (kx > k_end) LSX_TRY(getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, kx));
                 return getrf_lookahead_x<T>(h, n, A, lda, d_ipiv, d_info, Tinv, kx);
             }
         }
-        return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end, want_partition);
+        return getrf_lookahead<T>(h, n, A, lda, d_ipiv, d_info, Tinv, k_end);
     }
     return LSX_OK;
 }
@@ -947,8 +882,6 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ev_next) (void)hipEventDestroy(h->ev_next);
     if (h->ev_start) (void)hipEventDestroy(h->ev_start);
     if (h->ev_done) (void)hipEventDestroy(h->ev_done);
-    if (h->part_update) (void)hipStreamDestroy(h->part_update);
-    if (h->part_panel) (void)hipStreamDestroy(h->part_panel);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1056,7 +989,7 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_debug")) {
         h->panel_debug = value != 0;
     } else if (!strcmp(key, "lookahead")) {
-        LSX_ARG(value >= 0 && value <= 3);
+        LSX_ARG(value == 0 || value == 1);
         h->lookahead = value;
     } else if (!strcmp(key, "lookahead_min")) {
         LSX_ARG(value >= 0);

@@ -84,8 +84,6 @@ struct lsx_handle_s {
     hipEvent_t ev_panel = nullptr, ev_next = nullptr, ev_start = nullptr, ev_done = nullptr;
     // look-ahead with a CU partition (lookahead = 2): the trailing update runs on a stream masked to
     // one set of CUs, the panel on a stream masked to the others, so both are resident at once
-    hipStream_t part_update = nullptr, part_panel = nullptr;
-    int part_panel_cus = 0;
     // tunables
     int nb = 128;        // panel width (<= 128)
     int kblock = 1;      // panels per trailing update: update depth K = kblock * nb

@@ -477,15 +477,14 @@ __device__ __forceinline__ float s2_row_sum(const float v) {
     return s1 + __uint_as_float(s2_rows_partner16(__float_as_uint(s1)));
 }
 
-template <typename T, bool THROUGH = true>
+template <typename T>
 __device__ __forceinline__ void s2_store_gran(const __amdgpu_buffer_rsrc_t &r, const int idx, const T v, const unsigned tag) {
     unsigned long long bits;
     if (sizeof(T) == 8) bits = (unsigned long long)__double_as_longlong((double)v);
     else bits = (unsigned long long)__float_as_uint((float)v);
     u4 g;
     g.x = (unsigned)bits; g.y = (unsigned)(bits >> 32); g.z = tag; g.w = 0u;
-    if (THROUGH) __builtin_amdgcn_raw_buffer_store_b128(g, r, idx * (int)sizeof(XGran), 0, 16);   // write-through: device scope
-    else __builtin_amdgcn_raw_buffer_store_b128(g, r, idx * (int)sizeof(XGran), 0, 0);            // plain: this XCD's L2
+    __builtin_amdgcn_raw_buffer_store_b128(g, r, idx * (int)sizeof(XGran), 0, 16);   // write-through: device scope
 }
 template <typename T>
 __device__ __forceinline__ T s2_gran_value(const u4 &g) {
@@ -497,7 +496,7 @@ __device__ __forceinline__ T s2_gran_value(const u4 &g) {
 template <typename T, int NR, bool LOWER>
 __global__ __launch_bounds__(S2_THREADS) void trsv2_kernel(int n, int H, const T *__restrict__ LU, int lda,
                                                           const T *__restrict__ inv128T, const T *__restrict__ Rhs,
-                                                          T *__restrict__ Out, int ldo, int nout, XGran *xg, XGran *pg, XGran *xl,
+                                                          T *__restrict__ Out, int ldo, int nout, XGran *xg, XGran *pg,
                                                           unsigned epoch, int *status, int spin_limit,
                                                           unsigned long long *dbg) {
     // dbg != nullptr (development, LSX_S2_DBG): 100 MHz stamps of the owner of every block row, 8 per row
@@ -520,10 +519,9 @@ __global__ __launch_bounds__(S2_THREADS) void trsv2_kernel(int n, int H, const T
     if (!owner && first >= limit) return;                  // a helper without blocks: the owner does not wait for it
     const __amdgpu_buffer_rsrc_t r_x = __builtin_amdgcn_make_buffer_rsrc(xg, 0, NB * SB * NR * (int)sizeof(XGran), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(pg, 0, NB * H * SB * NR * (int)sizeof(XGran), 0x00020000);
-    // x_i a second time, by PLAIN stores: they stay in the writer's L2, where the next owner's polls find them half a
-    // microsecond earlier than the write-through copy IF it sits on the same XCD (H = 8: every owner has blockIdx % 8 == 0).
-    // Nothing depends on that being so: the owner's last poll reads both copies and takes whichever is valid.
-    const __amdgpu_buffer_rsrc_t r_l = __builtin_amdgcn_make_buffer_rsrc(xl, 0, NB * SB * NR * (int)sizeof(XGran), 0x00020000);
+    // (Tried: x_i a second time by plain stores, polled by the next owner beside the write-through copy -- with H = 8
+    // all owners sit on one XCD.  The hop got LONGER, 0.93 instead of 0.76 us: the extra loads per poll cost more than
+    // the L2-local copy gains.)
     if (tid == 0) s_fail = 0;
     __syncthreads();
 
@@ -578,7 +576,6 @@ __global__ __launch_bounds__(S2_THREADS) void trsv2_kernel(int n, int H, const T
             const bool last_own = owner && s + stride >= limit && h_late != 0;
             const bool with_late = NR <= 2 && last_own;
             if (NR > 2 && last_own) poll_partial(h_late);
-            const bool with_local = NR <= 2 && owner && s + stride >= limit;   // the previous owner's plain-store copy
             T val[2][NR], pv[2][NR <= 2 ? NR : 1];
             int spins = 0;
             for (;;) {
@@ -589,17 +586,6 @@ __global__ __launch_bounds__(S2_THREADS) void trsv2_kernel(int n, int H, const T
 #pragma unroll
                     for (int q = 0; q < NR; ++q)
                         g[t][q] = __builtin_amdgcn_raw_buffer_load_b128(r_x, ((j * SB + lane + 64 * t) * NR + q) * (int)sizeof(XGran), oz, 16);
-                if constexpr (NR <= 2) {
-                    if (with_local) {
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int q = 0; q < NR; ++q) {
-                                const u4 gl = __builtin_amdgcn_raw_buffer_load_b128(r_l, ((j * SB + lane + 64 * t) * NR + q) * (int)sizeof(XGran), oz, 16);
-                                if (gl.z == epoch) g[t][q] = gl;
-                            }
-                    }
-                }
                 bool ok = true;
                 if constexpr (NR <= 2) {
                     if (with_late) {
@@ -766,7 +752,6 @@ __global__ __launch_bounds__(S2_THREADS) void trsv2_kernel(int n, int H, const T
         const T v = s2_row_sum(v0);
         if (part == 0) {
             const T vv = grow < n ? v : T(0);
-            if (NR <= 2) s2_store_gran<T, false>(r_l, grow * NR + q, vv, epoch);   // the next owner's copy first
             s2_store_gran<T>(r_x, grow * NR + q, vv, epoch);
             if (grow < n && q < nout) Out[(size_t)grow * ldo + q] = v;
         }
@@ -801,12 +786,25 @@ __global__ __launch_bounds__(256) void solve_prep_kernel(int n, int nrhs, int NR
         const int lane = tid & 63, wave = tid >> 6;
         const int r0 = blk * VB;
         const int nb64 = (n + VH - 1) / VH;
-        for (int e = tid; e < VH * VH; e += 256) {
-            const int ii = e / VH, jj = e % VH;
-            X11[ii * VLD + jj] = inv64[(size_t)(2 * blk) * VH * VH + e];
-            X22[ii * VLD + jj] = (2 * blk + 1 < nb64) ? inv64[(size_t)(2 * blk + 1) * VH * VH + e] : (ii == jj ? T(1) : T(0));
-            const int gi = lower ? r0 + VH + ii : r0 + ii, gj = lower ? r0 + jj : r0 + VH + jj;
-            OFF[ii * VLD + jj] = (gi < n && gj < n) ? LU[(size_t)gi * lda + gj] : T(0);
+        {   // all 48 loads of a thread in flight at once (one iteration at a time they were 16 serial memory latencies:
+            // most of the 27 us this launch took at first)
+            constexpr int NE = VH * VH / 256;
+            T v11[NE], v22[NE], vof[NE];
+#pragma unroll
+            for (int t = 0; t < NE; ++t) {
+                const int e = tid + 256 * t, ii = e / VH, jj = e % VH;
+                v11[t] = inv64[(size_t)(2 * blk) * VH * VH + e];
+                v22[t] = (2 * blk + 1 < nb64) ? inv64[(size_t)(2 * blk + 1) * VH * VH + e] : (ii == jj ? T(1) : T(0));
+                const int gi = lower ? r0 + VH + ii : r0 + ii, gj = lower ? r0 + jj : r0 + VH + jj;
+                vof[t] = (gi < n && gj < n) ? LU[(size_t)gi * lda + gj] : T(0);
+            }
+#pragma unroll
+            for (int t = 0; t < NE; ++t) {
+                const int e = tid + 256 * t, ii = e / VH, jj = e % VH;
+                X11[ii * VLD + jj] = v11[t];
+                X22[ii * VLD + jj] = v22[t];
+                OFF[ii * VLD + jj] = vof[t];
+            }
         }
         __syncthreads();
         if (lower) v_gemm64<T>(OFF, X11, W, T(1), wave, lane);
@@ -898,7 +896,7 @@ int lu_solve_few_rhs2(lsx_handle_t h, int n, int nrhs, int nr, const T *LU, int 
     while (2 * H * NB <= h->num_cu && H < 8) H *= 2;     // every workgroup resident at once: one per CU (9 waves of 168 registers)
     if (nr >= 8 && H > 4) H = 4;                           // 8 right-hand sides: the helpers' partial sums are 8 x the traffic
     const size_t xbytes = (size_t)NB * SB * nr * sizeof(XGran), pbytes = xbytes * H;
-    const size_t need = 2 * (2 * xbytes + pbytes) + 256;
+    const size_t need = 2 * (xbytes + pbytes) + 256;
     if (need > h->xchg_bytes) {
         // a fresh, zeroed area: tags of another life of the memory must not pass for this handle's epochs
         LSX_HIP(hipStreamSynchronize(h->stream));
@@ -914,8 +912,8 @@ int lu_solve_few_rhs2(lsx_handle_t h, int n, int nrhs, int nr, const T *LU, int 
         h->xchg_epoch = 1;
     }
     ProfScope ps(h, LSX_PROF_TRSM, 2.0 * n * (double)n * nrhs, 2.0 * sizeof(T) * n * (double)n);
-    XGran *xgL = (XGran *)((char *)h->xchg + 256), *pgL = (XGran *)((char *)xgL + xbytes), *xlL = (XGran *)((char *)pgL + pbytes);
-    XGran *xgU = (XGran *)((char *)xlL + xbytes), *pgU = (XGran *)((char *)xgU + xbytes), *xlU = (XGran *)((char *)pgU + pbytes);
+    XGran *xgL = (XGran *)((char *)h->xchg + 256), *pgL = (XGran *)((char *)xgL + xbytes);
+    XGran *xgU = (XGran *)((char *)pgL + pbytes), *pgU = (XGran *)((char *)xgU + xbytes);
     int *status = h->dev_status + 1;
     LSX_TRY(launch_trtri_both<T>(h, n, LU, lda, inv64L, inv64U));
     LSX_HIP(hipFuncSetAttribute((const void *)solve_prep_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
@@ -932,9 +930,9 @@ int lu_solve_few_rhs2(lsx_handle_t h, int n, int nrhs, int nr, const T *LU, int 
     }
 #define S2_LAUNCH(NRV)                                                                                                    \
     hipLaunchKernelGGL((trsv2_kernel<T, NRV, true>), dim3(NB * H), dim3(S2_THREADS), 0, h->stream, n, H, LU, lda,          \
-                       (const T *)inv128L, (const T *)Bp, Y, NRV, NRV, xgL, pgL, xlL, h->xchg_epoch, status, h->spin_limit, dbgL); \
+                       (const T *)inv128L, (const T *)Bp, Y, NRV, NRV, xgL, pgL, h->xchg_epoch, status, h->spin_limit, dbgL); \
     hipLaunchKernelGGL((trsv2_kernel<T, NRV, false>), dim3(NB * H), dim3(S2_THREADS), 0, h->stream, n, H, LU, lda,         \
-                       (const T *)inv128U, (const T *)Y, B, ldb, nrhs, xgU, pgU, xlU, h->xchg_epoch, status, h->spin_limit, dbgU)
+                       (const T *)inv128U, (const T *)Y, B, ldb, nrhs, xgU, pgU, h->xchg_epoch, status, h->spin_limit, dbgU)
     switch (nr) {
         case 1: S2_LAUNCH(1); break;
         case 2: S2_LAUNCH(2); break;

@@ -170,7 +170,7 @@ def test_getrf_cooperative_panel_matches_cpu_twin(la, n):
 
     try:
         base = run(panel=3, panel_nt=0, panel_rt=4, lookahead=0, kblock=1, lookahead_min=128)
-        for nt, rt, look in ((256, 4, 0), (512, 4, 0), (512, 8, 0), (0, 4, 1), (0, 4, 2)):
+        for nt, rt, look in ((256, 4, 0), (512, 4, 0), (512, 8, 0), (0, 4, 1)):
             LUp, ipivp, infop = run(panel=3, panel_nt=nt, panel_rt=rt, lookahead=look)
             assert infop == 0 and np.array_equal(ipivp, base[1]) and np.array_equal(LUp, base[0]), \
                 f"pipelined panel nt={nt} rt={rt} lookahead={look} differs"
@@ -561,7 +561,7 @@ def test_full_size_lu_invariants(dev, n, kind):
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
     """The look-ahead driver (default above 7168 / 11264) forced onto small and odd orders: last panel narrower
-    than nb, odd leading dimension (no 16-byte paths), fewer tiles than CUs, partition fall-back.  Same bits as
+    than nb, odd leading dimension (no 16-byte paths), fewer tiles than CUs.  Same bits as
     the sequential driver, for every variant."""
     import torch
 
@@ -574,7 +574,7 @@ def test_lookahead_driver_on_ragged_sizes_is_bit_identical(dev, n, dtype):
     try:
         dev.h.set_option("lookahead_min", 128)
         # last entry: hand-over from the shared-CU schedule to the XCD-scope driver forced at 2/5 of the order
-        for mode, look, xl in ((3, 0, 0), (3, 1, 0), (3, 2, 0), (3, 3, 0), (4, 0, 0), (4, 1, 0), (4, 1, max(128, n * 2 // 5))):
+        for mode, look, xl in ((3, 0, 0), (3, 1, 0), (4, 0, 0), (4, 1, 0), (4, 1, max(128, n * 2 // 5))):
             dev.h.set_option("panel", mode)
             dev.h.set_option("lookahead", look)
             dev.h.set_option("xrows_limit", xl)
@@ -703,8 +703,8 @@ def test_structured_inverse_equals_the_plain_solve_of_the_permuted_identity(dev,
 
 
 def test_lookahead_variants_are_bit_identical_at_8192(dev):
-    """Look-ahead (panel k+1 under the update of step k, update and panel on disjoint CU sets) only
-    reorders launches: the factors must not change by a single bit."""
+    """Look-ahead (panel k+1 under the update of step k; with panel = 4 on an XCD of its own) only reorders
+    launches: the factors must not change by a single bit."""
     import torch
 
     from linalg_solver_amd import gen
@@ -714,7 +714,7 @@ def test_lookahead_variants_are_bit_identical_at_8192(dev):
     dev.fill_(A0, gen.U11, 4)
     outs = []
     try:
-        for mode, look in ((3, 0), (3, 1), (3, 2), (4, 0), (4, 1)):
+        for mode, look in ((3, 0), (3, 1), (4, 0), (4, 1)):
             dev.h.set_option("panel", mode)
             dev.h.set_option("lookahead", look)
             LU = A0.clone()
@@ -944,7 +944,11 @@ def test_fp32_inverse_determinant_and_rank(la):
 
 def test_full_size_fp32_solution_within_1e4_of_the_fp64_solution(dev):
     """config 5 at its own size: 8192 x 8192 fp32 factors, 4 right-hand sides; the refined solution against the
-    fp64 GPU solution of the same system (which test_full_size_lu_invariants holds to a 1e-9 backward error)."""
+    fp64 GPU solution of the same system (which test_full_size_lu_invariants holds to a 1e-9 backward error).
+    The bound: BASELINE asks for 1e-4.  This test first asserted 1e-9 for the refined fp64-accumulated solution,
+    which three sweeps miss at this size (5.97e-9 measured in round 2: each sweep gains about two digits from
+    cond * eps32 ~ 1e-2); it was set to 1e-6 -- a hundred times inside the required tolerance -- rather than adding
+    a fourth sweep to the default."""
     import torch
 
     from linalg_solver_amd import gen
