@@ -433,6 +433,17 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     return launch_laswp_left_all<T>(h, A, lda, k0, nb, nsteps, h->moves_all);
 }
 
+// Workspaces of one factorisation of order n: scratch (panel partials, gather lists, three XCD-scope exchange areas
+// and the driver's words) and ws2 (block inverses, two sets: the look-ahead driver alternates).  One computation for
+// getrf_dev and the multi-device driver (mg.hip), so the two cannot drift apart.
+int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem) {
+    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(elem * 2 * (size_t)n) +
+                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 3 * panel_x_area_bytes(h, n, elem) + 16384 +
+                                  ((size_t)n / 16 + 2) * 40));
+    const size_t tinv_elems = (size_t)((h->nb * h->kblock + 63) / 64) * 64 * 64;
+    return grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * elem));   // x2: the look-ahead driver alternates
+}
+
 // ---------------------------------------------------------------- blocked LU driver
 template <typename T>
 static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int *d_info) {
@@ -440,12 +451,7 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     if (n == 0) return LSX_OK;
     const int nb = h->nb;
     struct MfmaOnly { lsx_handle_t h; MfmaOnly(lsx_handle_t h_) : h(h_) { h->gemm_mfma_only = true; } ~MfmaOnly() { h->gemm_mfma_only = false; } } mfma_only(h);
-    // scratch: panel partials (and rref rows); internal ws: Tinv of the current panel
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(sizeof(T) * 2 * (size_t)n) +
-                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 3 * panel_x_area_bytes(h, n, sizeof(T)) + 16384 +
-                                  ((size_t)n / 16 + 2) * 40));
-    const size_t tinv_elems = (size_t)((nb * h->kblock + 63) / 64) * 64 * 64;
-    LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * sizeof(T))));   // x2: the look-ahead driver alternates
+    LSX_TRY(ensure_getrf_workspace(h, n, sizeof(T)));
     T *Tinv = (T *)h->ws2;
     if (!d_info) d_info = h->dev_status + 2;   // a time-out must be recorded somewhere: lsx_check_status reads it
     LSX_HIP(hipMemsetAsync(d_info, 0, sizeof(int), h->stream));

@@ -159,6 +159,7 @@ struct lsx_handle_s {
 namespace lsx {
 
 int ensure_ws(lsx_handle_t h, size_t bytes);
+int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem);   // scratch + block-inverse workspace of one LU (api.hip)
 
 // RAII-less profiling bracket: call begin() before a launch group, end() after.
 struct ProfScope {

@@ -265,13 +265,13 @@ __global__ __launch_bounds__(256) void rrb_gather_u_kernel(int nrows, int jb, co
 template <typename T>
 __global__ __launch_bounds__(256) void rrb_finish_kernel(int m, int bar, T *__restrict__ W, int ldw,
                                                          const int32_t *__restrict__ pivots, int rank) {
-    const int i = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (i >= m) return;
-    if (i >= rank) { if (c < bar) W[(size_t)i * ldw + c] = T(0); return; }
-    if (c < rank) {   // thread c handles pivot column pc[c] of row i
-        const int pcol = pivots[2 * c + 1];
-        W[(size_t)i * ldw + pcol] = (c == i) ? T(1) : T(0);
+    for (int i = blockIdx.y; i < m; i += gridDim.y) {   // grid.y is capped at 65535 rows: the rest by stride
+        if (i >= rank) { if (c < bar) W[(size_t)i * ldw + c] = T(0); continue; }
+        if (c < rank) {   // thread c handles pivot column pc[c] of row i
+            const int pcol = pivots[2 * c + 1];
+            W[(size_t)i * ldw + pcol] = (c == i) ? T(1) : T(0);
+        }
     }
 }
 
@@ -366,7 +366,7 @@ int rref_blocked(lsx_handle_t h, int m, int n, int bar, T *W, int ldw, int32_t *
         LSX_TRY(launch_trsm_block<T>(h, 0, jb, ncols, Ublk, RB_W, Tinv, X, ldw));
         if (kb > 0) LSX_TRY(launch_gemm_sub<T>(h, kb, ncols, jb, L, RB_W, X, ldw, W + col0, ldw));
     }
-    hipLaunchKernelGGL(rrb_finish_kernel<T>, dim3((std::max(bar, rank) + 255) / 256, m), dim3(256), 0, s, m, bar, W, ldw, d_pivots, rank);
+    hipLaunchKernelGGL(rrb_finish_kernel<T>, dim3((std::max(bar, rank) + 255) / 256, std::min(m, 65535)), dim3(256), 0, s, m, bar, W, ldw, d_pivots, rank);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }

@@ -69,12 +69,13 @@ static int mg_free(std::vector<Dev> &D, int rc) {
     return rc;
 }
 
-int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *lda, int32_t *const *d_ipiv,
-                 int *const *d_info) {
-    Guard guard;
+// Everything that can fail lives in this body; getrf_mg_f64 below runs it and then ALWAYS goes through mg_free, which
+// waits for every compute and link stream of every device and releases the link streams, events and panel buffers:
+// an error in the middle neither leaks them nor returns while kernels and peer copies are still queued.
+static int getrf_mg_body(std::vector<Dev> &D, lsx_handle_t *hs, int P, int n, double *const *dA, const int *lda,
+                         int32_t *const *d_ipiv, int *const *d_info) {
     const int nb = hs[0]->nb;
     const int nblocks = (n + nb - 1) / nb;
-    std::vector<Dev> D(P);
     const size_t buf_bytes = MG_HDR + sizeof(double) * (size_t)n * nb;
     for (int d = 0; d < P; ++d) {
         Dev &x = D[d];
@@ -104,14 +105,14 @@ int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *l
             if (e == d) continue;
             if (D[e].dev != x.dev) (void)hipDeviceEnablePeerAccess(D[e].dev, 0);   // already enabled is fine
             (void)hipGetLastError();
-            if (hipStreamCreateWithFlags(&x.link[e], hipStreamNonBlocking) != hipSuccess) { set_error("getrf_mg: stream creation failed"); return mg_free(D, LSX_ERR_HIP); }
+            if (hipStreamCreateWithFlags(&x.link[e], hipStreamNonBlocking) != hipSuccess) { set_error("getrf_mg: stream creation failed"); return LSX_ERR_HIP; }
         }
         for (int p = 0; p < 2; ++p) {
-            if (hipMalloc((void **)&x.buf[p], buf_bytes) != hipSuccess) { set_error("getrf_mg: hipMalloc"); return mg_free(D, LSX_ERR_ALLOC); }
+            if (hipMalloc((void **)&x.buf[p], buf_bytes) != hipSuccess) { set_error("getrf_mg: hipMalloc"); return LSX_ERR_ALLOC; }
             if (hipEventCreateWithFlags(&x.packed[p], hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&x.freed[p], hipEventDisableTiming) != hipSuccess) {
                 set_error("getrf_mg: event creation failed");
-                return mg_free(D, LSX_ERR_HIP);
+                return LSX_ERR_HIP;
             }
         }
         // events of the copies THIS device issues (as source) towards each peer
@@ -121,7 +122,7 @@ int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *l
                     if (e != d && hipEventCreateWithFlags(&D[e].landed[((size_t)d * 2 + p) * MG_CHUNKS + c],
                                                           hipEventDisableTiming) != hipSuccess) {
                         set_error("getrf_mg: event creation failed");
-                        return mg_free(D, LSX_ERR_HIP);
+                        return LSX_ERR_HIP;
                     }
         LSX_HIP(hipMemsetAsync(d_info[d], 0, sizeof(int), x.comp));
         LSX_HIP(hipEventRecord(x.freed[0], x.comp));
@@ -271,29 +272,11 @@ int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *l
         return LSX_OK;
     };
 
-    // workspaces of the per-device kernels (scratch for the panel exchange, block inverses)
+    // workspaces of the per-device kernels: the one computation getrf_dev uses (api.hip), under each device's guard
     for (int d = 0; d < P; ++d) {
         LSX_HIP(hipSetDevice(D[d].dev));
-        int rc = LSX_OK;
-        {   // the same sizes getrf_dev reserves
-            lsx_handle_t h = hs[d];
-            const size_t need = ((16 * ((size_t)n / 32 + 2) + 255) & ~(size_t)255) + ((size_t)n / 32 + 2) * 5248 + 8192;
-            if (need > h->scratch_bytes) {
-                (void)hipStreamSynchronize(h->stream);
-                if (h->scratch) (void)hipFree(h->scratch);
-                h->scratch = nullptr; h->scratch_bytes = 0;
-                if (hipMalloc(&h->scratch, need) != hipSuccess) rc = LSX_ERR_ALLOC; else h->scratch_bytes = need;
-            }
-            const size_t tinv = 2 * (((size_t)((nb + 63) / 64) * 4096 * sizeof(double) + 255) & ~(size_t)255);
-            if (rc == LSX_OK && tinv > h->ws2_bytes) {
-                (void)hipStreamSynchronize(h->stream);
-                if (h->ws2) (void)hipFree(h->ws2);
-                h->ws2 = nullptr; h->ws2_bytes = 0;
-                if (hipMalloc(&h->ws2, tinv) != hipSuccess) rc = LSX_ERR_ALLOC; else h->ws2_bytes = tinv;
-            }
-            h->gemm_mfma_only = true;   // same summation order whatever the column split (as in getrf_dev)
-        }
-        if (rc != LSX_OK) { set_error("getrf_mg: workspace allocation failed"); return mg_free(D, rc); }
+        if (ensure_getrf_workspace(hs[d], n, sizeof(double)) != LSX_OK) { set_error("getrf_mg: workspace allocation failed"); return LSX_ERR_ALLOC; }
+        hs[d]->gemm_mfma_only = true;   // same summation order whatever the column split (as in getrf_dev)
     }
     struct MfmaOnly { std::vector<Dev> &D; ~MfmaOnly() { for (auto &d : D) d.h->gemm_mfma_only = false; } } mfma_only{D};
 
@@ -348,7 +331,15 @@ int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *l
             }
         }
     }
-    // everything queued: wait for all devices, release
+    return rc;
+}
+
+int getrf_mg_f64(lsx_handle_t *hs, int P, int n, double *const *dA, const int *lda, int32_t *const *d_ipiv,
+                 int *const *d_info) {
+    Guard guard;
+    std::vector<Dev> D(P);
+    const int rc = getrf_mg_body(D, hs, P, n, dA, lda, d_ipiv, d_info);
+    // everything queued (or abandoned half-way): wait for all devices, release
     return mg_free(D, rc);
 }
 

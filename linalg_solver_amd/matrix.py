@@ -251,7 +251,13 @@ class Matrix:
                 X = X[:, 0]
         # singular to working precision: the same test as the host path (smallest |pivot| against the largest entry)
         ratio = float(LU.diagonal().abs().min() / A.abs().max().clamp_min(1e-300))
-        if int(info.item()) != 0 or not (ratio > dense.EPS64 * n):
+        code = int(info.item())
+        if code < 0:
+            # a cooperative kernel timed out on the device (lsx.h: lsx_check_status): that is a failure of the run,
+            # not a property of the matrix -- never report it as "singular"
+            dev.h.check_status()
+            raise RuntimeError(f"device factorisation failed (info = {code})")
+        if code != 0 or not (ratio > dense.EPS64 * n):
             return Matrix.NoSolution()
         return X
 
