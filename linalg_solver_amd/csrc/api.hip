@@ -878,6 +878,7 @@ int lsx_destroy(lsx_handle_t h) {
     if (h->ws2) (void)hipFree(h->ws2);
     if (h->ws3) (void)hipFree(h->ws3);
     if (h->ws4) (void)hipFree(h->ws4);
+    if (h->ws6) (void)hipFree(h->ws6);
     if (h->xchg) (void)hipFree(h->xchg);
     if (h->ws5) (void)hipFree(h->ws5);
     if (h->scratch) (void)hipFree(h->scratch);
@@ -989,6 +990,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_xcd")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_xcd = value;
+    } else if (!strcmp(key, "rref_first_fast")) {   // 0: LSX_PIVOT_FIRST always through the per-column kernels (cross-check)
+        LSX_ARG(value == 0 || value == 1);
+        h->rref_first_fast = value;
     } else if (!strcmp(key, "chain_wait_limit")) {   // tests: 0 makes the chain's wait for the update's first tile column a time-out
         LSX_ARG(value >= 0);
         h->chain_wait_limit = value;
@@ -1022,6 +1026,8 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "panel_nt")) *value = h->panel_nt;
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
+    else if (!strcmp(key, "rref_first_fast")) *value = h->rref_first_fast;
+    else if (!strcmp(key, "rref_first_used")) *value = h->rref_first_used;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "diag_panels")) {
 #ifdef LSX_DIAG_PANELS
@@ -1123,6 +1129,120 @@ static int det_host(lsx_handle_t h, int n, const T *A, int lda, double *sign, do
     return LSX_OK;
 }
 
+
+// ---------------------------------------------------------------- first-rule row reduction, blocked
+// The reference pivots on the FIRST row whose entry is non-zero (linalg.py:548-552).  With rank < m or bar < n that
+// choice shows in the result: the carried-along columns of a pivot row are a combination of exactly the original rows
+// that became pivot rows, and which rows those are depends on the rule.  The per-column kernels (kernels_rref.hip)
+// reproduce the rule at one read + write of the live matrix per column -- ~8 TB for an 8192^2 matrix of rank 4096.
+// This form gets the same result from three pieces of the fast machinery:
+//   1. rank r and the pivot columns pc from the blocked max-rule reduction of a copy (the rule does not change them);
+//   2. G = A[:, pc] (m x r, full column rank) factored P G = L U by the blocked LU with the panel kernel under the FIRST
+//      rule: P and the r pivot rows in order are the reference's own interchanges (a swap there is a swap here);
+//   3. with P A = [A1; A2]:  top rows  A1[:, pc]^-1 A1  (the unique rows spanned by the pivot rows whose pivot columns are
+//      unit vectors),  other rows  A2 - A2[:, pc] * top  (MFMA update) -- then exact unit / zero entries as above.
+//      The factors of step 2 only NAME the rows: without magnitude pivoting their multipliers grow (3e-7 relative error
+//      in a 520 x 300 integer case of rank 130 when they were used for the values), so A1[:, pc] is factored once more
+//      with partial pivoting and the values come from that solve.
+// fp64, up to 8192 rows (one XCD's panel); returns 1 for anything else and when the factorisation of G meets a column
+// without a candidate above the tolerance (the two rules then disagree on the rank: the per-column pass decides).
+// Synchronises the stream twice (rank and max |a| are needed on the host for the launch shapes).
+static int rref_first_fast(lsx_handle_t h, int m, int n, int bar, double *R, int ldr, int32_t *d_pivots, int *d_rank, double tol) {
+    typedef double T;
+    h->rref_first_used = 0;
+    const bool dbg = getenv("LSX_RREF_DEBUG") != nullptr;   // development: say why the blocked form was not taken
+    if (!h->rref_first_fast || !h->rref_blocked || h->panel_mode != 4 || m > 8192 || (size_t)m * bar < (size_t)256 * 256) {
+        if (dbg) fprintf(stderr, "rref_first_fast: not applicable (fast %d blocked %d panel %d m %d bar %d)\n", h->rref_first_fast, h->rref_blocked, h->panel_mode, m, bar);
+        return 1;
+    }
+    const int nb = h->nb;
+    const int rmax = m < bar ? m : bar;
+    const int ldw = ld_for(n), ldg = ld_for(rmax);
+    const size_t wbytes = pad256(sizeof(T) * (size_t)m * ldw), gbytes = pad256(sizeof(T) * (size_t)m * ldg);
+    LSX_TRY(grow(&h->ws6, &h->ws6_bytes, wbytes + gbytes + 2 * pad256(sizeof(int32_t) * (size_t)m) + 1024));
+    Carver c(h->ws6);
+    T *W = c.take<T>((size_t)m * ldw);
+    T *Gm = c.take<T>((size_t)m * ldg);
+    int32_t *ipiv = c.take<int32_t>(m);
+    int32_t *ipiv2 = c.take<int32_t>(m);
+    int *ginfo = c.take<int>(2);
+    double *amax = c.take<double>(1);
+    // 1. rank and pivot columns
+    LSX_TRY(launch_copy2d<T>(h, m, n, R, ldr, W, ldw));
+    const int rb = rref_blocked<T>(h, m, n, bar, W, ldw, d_pivots, d_rank, tol, LSX_PIVOT_MAX);
+    if (dbg && rb != LSX_OK) fprintf(stderr, "rref_first_fast: rref_blocked returned %d\n", rb);
+    if (rb != LSX_OK) return rb;   // 1: not for the blocked form either
+    LSX_TRY(launch_amax<T>(h, m, bar, R, ldr, amax));
+    int r = 0;
+    double hmax = 0.0;
+    LSX_HIP(hipMemcpyAsync(&r, d_rank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipMemcpyAsync(&hmax, amax, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (r <= 0) { h->rref_first_used = 1; return LSX_OK; }      // nothing to pivot on: R is its own reduced form
+    if (r == m) {   // every row is a pivot row: the result does not depend on the rule
+        h->rref_first_used = 1;
+        return launch_copy2d<T>(h, m, n, W, ldw, R, ldr);
+    }
+    // the same threshold the row reductions use (kernels_rref.hip: 32 eps max(m, n) max|a|), fixed at the input's scale
+    const double ftol = tol >= 0 ? tol : 32.0 * 2.220446049250313e-16 * (double)(m > n ? m : n) * hmax;
+    // 2. P G = L U under the first-non-zero rule
+    LSX_TRY(launch_gather_pivot_cols<T>(h, m, r, 0, R, ldr, d_pivots, Gm, ldg));
+    LSX_TRY(ensure_getrf_workspace(h, m, sizeof(T)));
+    T *Tinv = (T *)h->ws2;
+    LSX_HIP(hipMemsetAsync(ginfo, 0, sizeof(int), h->stream));
+    struct MfmaOnly { lsx_handle_t h; MfmaOnly(lsx_handle_t h_) : h(h_) { h->gemm_mfma_only = true; } ~MfmaOnly() { h->gemm_mfma_only = false; } } mfma_only(h);
+    for (int k = 0; k < r; k += nb) {
+        const int jb = (r - k < nb) ? r - k : nb;
+        T *Gkk = Gm + (size_t)k * ldg + k;
+        h->moves_valid = false;
+        const int pr = panel_xcd_first(h, m - k, jb, Gkk, ldg, k, k, ipiv + k, ginfo, ftol);
+        if (dbg && pr != LSX_OK) fprintf(stderr, "rref_first_fast: panel at %d returned %d\n", k, pr);
+        if (pr != LSX_OK) return pr;
+        if (!h->moves_valid) { set_error("rref_first: panel without a gather list"); return LSX_ERR_INTERNAL; }
+        LSX_TRY(launch_laswp_moves_around<T>(h, r, Gm, ldg, k, k, jb));         // the other columns of G
+        const int rest = r - k - jb;
+        if (rest > 0) {
+            T *G12 = Gkk + jb;
+            LSX_TRY(launch_trtri<T>(h, 1, jb, Gkk, ldg, Tinv));
+            LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest, Gkk, ldg, Tinv, G12, ldg));
+            LSX_TRY(launch_gemm_sub<T>(h, m - k - jb, rest, jb, Gkk + (size_t)jb * ldg, ldg, G12, ldg, Gkk + (size_t)jb * ldg + jb, ldg));
+        }
+    }
+    int hinfo = 0;
+    LSX_HIP(hipMemcpyAsync(&hinfo, ginfo, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    LSX_HIP(hipStreamSynchronize(h->stream));
+    if (dbg) fprintf(stderr, "rref_first_fast: rank %d, max|a| %g, tol %g, info of the first-rule LU %d\n", r, hmax, ftol, hinfo);
+    if (hinfo != 0) {
+        // a pivot column of the max rule without a first-rule candidate (or a time-out): R is still the input -- the
+        // per-column pass decides
+        if (hinfo < 0) (void)hipMemsetAsync(h->dev_status, 0, 3 * sizeof(int), h->stream);
+        return 1;
+    }
+    // 3. P A, then the top rows A1[:, pc]^-1 A1 (a partial-pivot factorisation of the r x r block: the first-rule
+    // factors above only named the rows) and the rest A2 - A2[:, pc] * top
+    for (int k = 0; k < r; k += nb) LSX_TRY(launch_laswp<T>(h, n, R, ldr, k, (r - k < nb) ? r - k : nb, ipiv + k));
+    LSX_TRY(launch_gather_pivot_cols<T>(h, r, r, 0, R, ldr, d_pivots, Gm, ldg));
+    LSX_TRY(getrf_dev<T>(h, r, Gm, ldg, ipiv2, ginfo + 1));
+    LSX_TRY(getrs_dev<T>(h, r, n, Gm, ldg, ipiv2, R, ldr));
+    LSX_TRY(launch_gather_pivot_cols<T>(h, m, r, r, R, ldr, d_pivots, Gm, ldg));    // rows >= r of G <- (P A)[r:, pc]
+    LSX_TRY(launch_gemm_sub<T>(h, m - r, n, r, Gm + (size_t)r * ldg, ldg, R, ldr, R + (size_t)r * ldr, ldr));
+    LSX_TRY(launch_rref_finish<T>(h, m, bar, R, ldr, d_pivots, r));
+    h->rref_first_used = 1;
+    return LSX_OK;
+}
+
+// Row reduction under either rule: the blocked first-rule form where it applies, else kernels_rref.hip / _blk.hip.
+template <typename T>
+static int rref_any(lsx_handle_t h, int m, int n, int bar, T *R, int ldr, int32_t *d_pivots, int *d_rank, double tol, int pivot_rule) {
+    if constexpr (sizeof(T) == 8) {
+        if (pivot_rule == LSX_PIVOT_FIRST) {
+            const int rc = rref_first_fast(h, m, n, bar, R, ldr, d_pivots, d_rank, tol);
+            if (rc != 1) return rc;   // done, or a real error; 1: not applicable, R untouched
+        }
+    }
+    return launch_rref<T>(h, m, n, bar, R, ldr, d_pivots, d_rank, tol, pivot_rule);
+}
+
 template <typename T>
 static int rref_host(lsx_handle_t h, int m, int n, int bar_col, const T *A, int lda, T *R, int ldr, int32_t *pivots,
                      int *rank, double tol, int pivot_rule) {
@@ -1139,7 +1259,7 @@ static int rref_host(lsx_handle_t h, int m, int n, int bar_col, const T *A, int 
     int32_t *dp = c.take<int32_t>(2 * (size_t)np);
     int *drank = c.take<int>(1);
     LSX_TRY(h2d<T>(h, m, n, A, lda, dR, ld));
-    LSX_TRY(launch_rref<T>(h, m, n, bar, dR, ld, dp, drank, tol, pivot_rule));
+    LSX_TRY(rref_any<T>(h, m, n, bar, dR, ld, dp, drank, tol, pivot_rule));
     LSX_TRY(d2h<T>(h, m, n, dR, ld, R, ldr));
     int hr = 0;
     LSX_HIP(hipMemcpyAsync(&hr, drank, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1384,7 +1504,7 @@ int lsx_rref_f64_dev(lsx_handle_t h, int m, int n, int bar_col, double *dR, int 
     const int bar = bar_col > 0 ? bar_col : n - 1;
     LSX_ARG(bar <= n);
     LSX_TRY(ensure_scratch(h, 256 + 2 * sizeof(double) * (size_t)n + 4096 + 2 * (size_t)m));   // + the blocked form's row-group candidates
-    return launch_rref<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol, pivot_rule);
+    return rref_any<double>(h, m, n, bar, dR, ldr, d_pivots, d_rank, tol, pivot_rule);
 }
 
 int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int row0, int32_t *d_ipiv,

@@ -134,6 +134,10 @@ struct lsx_handle_s {
     void *xchg = nullptr;    // few-RHS solve (kernels_trsv.hip, third form): exchange granules validated by an epoch, never cleared
     size_t xchg_bytes = 0;
     unsigned xchg_epoch = 0;
+    void *ws6 = nullptr;     // first-rule row reduction: a copy of the matrix, its pivot columns, interchanges
+    size_t ws6_bytes = 0;
+    int rref_first_fast = 1; // 1: large fp64 inputs under LSX_PIVOT_FIRST take the blocked form (option rref_first_fast)
+    int rref_first_used = 0; // read-only option: 1 if the last LSX_PIVOT_FIRST reduction took the blocked form
     void *ws4 = nullptr;     // residual / correction of the mixed-precision solve
     size_t ws4_bytes = 0;
     // small fixed device scratch: pivot search partials, flags, info words
@@ -159,7 +163,15 @@ struct lsx_handle_s {
 namespace lsx {
 
 int ensure_ws(lsx_handle_t h, size_t bytes);
-int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem);   // scratch + block-inverse workspace of one LU (api.hip)
+int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem);
+// XCD-scope panel under the reference's first-non-zero pivot rule (kernels_panel_x.hip); 1 = shape not served
+int panel_xcd_first(lsx_handle_t h, int m, int jb, double *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info, double tol);
+template <typename T>
+int launch_gather_pivot_cols(lsx_handle_t h, int m, int r, int row_lo, const T *src, int lds, const int32_t *d_pivots, T *dst, int ldd);
+template <typename T>
+int launch_rref_finish(lsx_handle_t h, int m, int bar, T *W, int ldw, const int32_t *d_pivots, int rank);
+template <typename T>
+int rref_blocked(lsx_handle_t h, int m, int n, int bar, T *W, int ldw, int32_t *d_pivots, int *d_rank, double tol, int pivot_rule);   // scratch + block-inverse workspace of one LU (api.hip)
 
 // RAII-less profiling bracket: call begin() before a launch group, end() after.
 struct ProfScope {

@@ -72,11 +72,18 @@ __device__ __forceinline__ T bits_value(unsigned lo, unsigned hi) {
     return (T)__uint_as_float(lo);
 }
 
-template <typename T, int RT, bool DBG, bool XCD>
+// FIRST (the reference's pivot rule, linalg.py:548-552, for the rank-deficient / bar_col < n row reductions of api.hip's
+// rref_first): the pivot of a column is not the largest entry but the FIRST row in the current row order whose entry
+// exceeds `tol`.  Rows do not move inside this kernel, so every lane carries the current POSITION of its rows (an
+// interchange j <-> p sends the row that sat at position j down to p); candidates are ordered by position, the
+// position travels in bits 8..21 of the header's epoch word, and a column without a candidate is reported like an
+// exactly zero pivot (info = column + 1).  Everything else -- record, exchange, bookkeeping, scatter -- is shared.
+template <typename T, int RT, bool DBG, bool XCD, bool FIRST = false>
 __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, int jb, T *__restrict__ P, int ldp,
                                              int row0, int col0, int32_t *__restrict__ ipiv,
                                              int *__restrict__ info, char *rec, XGran *far, int *status,
-                                             unsigned long long *dbg, int2 *__restrict__ moves, const int spin_limit) {
+                                             unsigned long long *dbg, int2 *__restrict__ moves, const int spin_limit,
+                                             const double tol = -1.0) {
     constexpr int NT = PX_NT, WC = PX_WC;
     constexpr int NW = NT / 64;   // waves
     constexpr int RB = 64 * RT;   // panel rows per workgroup
@@ -147,6 +154,20 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
 #pragma unroll
     for (int r = 0; r < RT; ++r)
         if (base + 64 * r + lane >= m) frozen |= 1u << r;
+    int pos[FIRST ? RT : 1];   // FIRST: current position of row r of this lane in the panel's row order
+    if (FIRST) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) pos[r] = base + 64 * r + lane;
+    }
+    constexpr unsigned EMASK = FIRST ? 0xffu : 0x7fffffffu;   // epoch bits of a header's fourth word
+    // the interchange of column j (winner row `win` sat at position wpos): whatever sat at position j goes to wpos
+    auto track_swap = [&](const int j, const int win, const int wpos) __attribute__((always_inline)) {
+        if (FIRST) {
+#pragma unroll
+            for (int r = 0; r < RT; ++r)
+                if (pos[r] == j && base + 64 * r + lane != win) pos[r] = wpos;
+        }
+    };
     bool failed = false;
     u4 hA = u4{0u, 0u, 0u, 0u}, hB = u4{0u, 0u, 0u, 0u};   // the two pre-issued header shots
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the tile is in registers before the column loop
@@ -202,10 +223,11 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
 #undef LSX_ST16
     };
     // header of column jn: {|a| of the candidate (fp64 bits), row (-1: none), epoch jn + 1 | sign << 31}
-    auto store_header = [&](const int jn, const double val, const int row, const bool neg)
+    auto store_header = [&](const int jn, const double val, const int row, const bool neg, const int rpos = 0)
                             __attribute__((always_inline)) {
         store16((unsigned)__double2loint(val), (unsigned)__double2hiint(val),
-                (unsigned)__builtin_amdgcn_readfirstlane(row), (unsigned)(jn + 1) | (neg ? 0x80000000u : 0u),
+                (unsigned)__builtin_amdgcn_readfirstlane(row),
+                (unsigned)(jn + 1) | (neg ? 0x80000000u : 0u) | (FIRST ? ((unsigned)rpos << 8) : 0u),
                 ((jn & 1) * G + g) * PX_REC, d_rec);
     };
     // granule of column jn: {value bits, epoch jn + 1, 0}
@@ -221,15 +243,21 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         constexpr int CN = decltype(CNt)::value;
         double nv = -1.0;
         int ni = NONE;
+        int np = NONE;   // FIRST: the candidate's position
 #pragma unroll
         for (int r = 0; r < RT; ++r) {   // rows of a lane ascend with r: the first maximum is the lowest row
             const double av = fabs((double)a[r][CN]);
-            const bool better = (((frozen >> r) & 1u) == 0u) & (av > nv);
+            bool better;
+            if (FIRST) better = (((frozen >> r) & 1u) == 0u) & (av > tol) & (pos[r] < np);
+            else better = (((frozen >> r) & 1u) == 0u) & (av > nv);
             nv = better ? av : nv;
             ni = better ? base + 64 * r + lane : ni;
+            if (FIRST) np = better ? pos[r] : np;
         }
         const unsigned long long kb = (ni != NONE) ? (unsigned long long)__double_as_longlong(nv) : 0ull;
-        const int win = argmax64_fast((unsigned)(kb >> 32), (unsigned)kb, ni);
+        // FIRST: the key is the position, inverted (the arg-max then finds the first row); positions are unique
+        const int win = FIRST ? argmax64_fast((ni != NONE) ? (unsigned)(0x7fffffff - np) : 0u, 0u, ni)
+                              : argmax64_fast((unsigned)(kb >> 32), (unsigned)kb, ni);
         const bool have = win != NONE;
         const int cl = have ? win - base : -1;
         if (have) {
@@ -239,7 +267,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
 #pragma unroll
                 for (int k = 0; k < RT; ++k)
                     if (ck == k) {
-                        store_header(jn, fabs((double)a[k][CN]), win, a[k][CN] < T(0));
+                        store_header(jn, fabs((double)a[k][CN]), win, a[k][CN] < T(0), FIRST ? pos[k] : 0);
 #pragma unroll
                         for (int c = (CN & 7) + 1; c < 8; ++c)
                             store_gran(d_rec, roff + 16 * c, a[k][(CN & 8) + c], jn);
@@ -346,6 +374,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             const int wl = wrow - base;
             if ((wl & 63) == lane) frozen |= 1u << (wl >> 6);
         }
+        if (valid) track_swap(j, wrow, inf.w);
         bool ok = true;
         if (act && wave > ow && has_cols) ok = far_update(I0{}, IWC{}, j, bg);
         if (stamp) STAMP(5)
@@ -383,7 +412,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         constexpr int CJ = decltype(CJt)::value;
         constexpr int JC = CJ & 7;        // column inside its 8-column block
         constexpr int CB = CJ & 8;        // tile column of the block's first column
-        constexpr bool FIRST = WC == 16 && CJ < 8;   // the wave's first block: its second block is "far" and follows behind
+        constexpr bool FIRSTB = WC == 16 && CJ < 8;   // the wave's first block: its second block is "far" and follows behind
         constexpr bool NEAR = JC < 7;     // the block has columns right of j
         const int par = j & 1;
         const bool more = j + 1 < jb;
@@ -394,17 +423,19 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         bool pend = lane < G;
         unsigned hlo = 0u, hhi = 0u, hneg = 0u;
         int hrow = NONE;
+        int hpos = 0;
         auto absorb = [&](const u4 &h) __attribute__((always_inline)) {
-            const bool ok = pend & ((h.w & 0x7fffffffu) == (unsigned)(j + 1));
+            const bool ok = pend & ((h.w & EMASK) == (unsigned)(j + 1));
             hlo = ok ? h.x : hlo;
             hhi = ok ? h.y : hhi;
             hneg = ok ? (h.w >> 31) : hneg;
+            if (FIRST) hpos = ok ? (int)((h.w >> 8) & 0x3fffu) : hpos;
             hrow = ok ? ((int)h.z >= 0 ? (int)h.z : NONE) : hrow;
             pend = ok ? false : pend;
         };
         // Shots in flight: in the second block and at a block start A (before the previous barrier) and B (after
         // it); inside the first block only A, and it has landed: the second block's far load behind it was waited for
-        constexpr bool TWO = !FIRST || JC == 0;
+        constexpr bool TWO = !FIRSTB || JC == 0;
         if (TWO) wait_a(); else wait_b();
         PX_MARK(1)
         absorb(hA);
@@ -419,9 +450,11 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             }
         }
         const bool hv = hrow != NONE;
-        const int win = argmax64_fast(hv ? hhi : 0u, hv ? hlo : 0u, hrow);
+        const int win = FIRST ? argmax64_fast(hv ? (unsigned)(0x7fffffff - hpos) : 0u, 0u, hrow)
+                              : argmax64_fast(hv ? hhi : 0u, hv ? hlo : 0u, hrow);
         const bool valid = (win != NONE) & !failed_now;
         const int bg = valid ? win / RB : 0;     // lane bg holds the winner's header
+        const int wpos = FIRST ? __builtin_amdgcn_readlane(hpos, bg) : 0;
         const unsigned plo = (unsigned)__builtin_amdgcn_readlane((int)hlo, bg);
         const unsigned phi = (unsigned)__builtin_amdgcn_readlane((int)hhi, bg);
         const bool pneg = __builtin_amdgcn_readlane((int)hneg, bg) != 0;
@@ -441,6 +474,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
             const int wl = win - base;
             if ((wl & 63) == lane) frozen |= 1u << (wl >> 6);
         }
+        if (valid) track_swap(j, win, wpos);
         T l[RT];
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
@@ -486,7 +520,7 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         if (NEAR && more) cl = choose_and_announce(std::integral_constant<int, (CJ < WC - 1 ? CJ + 1 : WC - 1)>{}, j + 1);
         PX_MARK(6)
         const bool act2 = act & !failed_now;
-        if (lane == 0) s_info[par] = make_int4(valid ? win : -1, (act2 ? 1 : 0) | (failed_now ? 2 : 0), cl, 0);
+        if (lane == 0) s_info[par] = make_int4(valid ? win : -1, (act2 ? 1 : 0) | (failed_now ? 2 : 0), cl, wpos);
         if (failed_now && !failed) {
             failed = true;
             if (lane == 0) atomicExch(status, 1);
@@ -495,10 +529,10 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
         STAMP(2)
         PX_MARK(7)
         __syncthreads();
-        if (!FIRST && NEAR && more) shot_async(hB, j + 1);
+        if (!FIRSTB && NEAR && more) shot_async(hB, j + 1);
         PX_MARK(8)
         STAMP(3)
-        if constexpr (FIRST) { if (more) {
+        if constexpr (FIRSTB) { if (more) {
             // the second block follows behind the barrier like any far block; at the end of the first block it is
             // brought up to date BEFORE its first column's candidate is chosen (second barrier: see follow)
             bool ok = true;
@@ -610,12 +644,12 @@ __device__ __forceinline__ void panel_x_body(const int G, const int g, int m, in
 // handshake: participant g stores 1 + its XCC id device-scope, everybody reads all G (bounded spin) and takes the
 // XCD-scope protocol only if all ids agree -- the decision is a function of the same G words for every
 // participant, so they all take the same branch.
-template <typename T, int RT, bool DBG>
+template <typename T, int RT, bool DBG, bool FIRST = false>
 __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int jb, T *__restrict__ P, int ldp, int row0, int col0,
                                                         int32_t *__restrict__ ipiv, int *__restrict__ info,
                                                         char *rec, XGran *far, int *status, unsigned long long *dbg,
                                                         int2 *__restrict__ moves, int *xcc, int *xcc_word,
-                                                        int spin_limit) {
+                                                        int spin_limit, double tol) {
     if (blockIdx.x & 7) return;
     LSX_TS(1);
     const int G = gridDim.x >> 3, g = blockIdx.x >> 3;
@@ -649,9 +683,9 @@ __global__ __launch_bounds__(PX_NT, PX_NT / 256) void panel_x_kernel(int m, int 
     }
     __syncthreads();
     if (s_same)
-        panel_x_body<T, RT, DBG, true>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit);
+        panel_x_body<T, RT, DBG, true, FIRST>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit, tol);
     else
-        panel_x_body<T, RT, DBG, false>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit);
+        panel_x_body<T, RT, DBG, false, FIRST>(G, g, m, jb, P, ldp, row0, col0, ipiv, info, rec, far, status, dbg, moves, spin_limit, tol);
 }
 
 // bytes of one exchange area for panels of up to m rows (0: not served)
@@ -664,7 +698,8 @@ size_t panel_x_area_bytes(lsx_handle_t h, int m, size_t elem) {
 
 // Returns 1 when the shape is outside what the kernel serves (caller falls back to the device-scope kernel).
 template <typename T, int RT>
-static int panel_xcd_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {
+static int panel_xcd_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info,
+                        const double first_tol = -1.0) {
     if (jb > PC_COLS) return 1;
     const int G = (m + 64 * RT - 1) / (64 * RT);
     if (G > 32 || 8 * G > 8 * h->num_cu) return 1;
@@ -686,12 +721,18 @@ static int panel_xcd_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, 
     XGran *far = (XGran *)(base + 256 + rec_bytes);
     if (!driver_clears) LSX_HIP(hipMemsetAsync(base, 0, h->panel_debug ? total : need, h->stream));
     unsigned long long *dbg = h->panel_debug ? (unsigned long long *)(base + dbg_off) : nullptr;
-    if (h->panel_debug)
+    if (first_tol >= 0.0) {   // the reference's first-non-zero rule (fp64, up to 8192 rows: callers check)
+        if constexpr (sizeof(T) == 8 && RT <= 4)
+            hipLaunchKernelGGL((panel_x_kernel<T, RT, false, true>), dim3(8 * G), dim3(PX_NT), 0, h->stream, m, jb, P, ldp, row0,
+                               col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit, first_tol);
+        else
+            return 1;
+    } else if (h->panel_debug)
         hipLaunchKernelGGL((panel_x_kernel<T, RT, true>), dim3(8 * G), dim3(PX_NT), 0, h->stream, m, jb, P, ldp, row0,
-                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit);
+                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit, -1.0);
     else
         hipLaunchKernelGGL((panel_x_kernel<T, RT, false>), dim3(8 * G), dim3(PX_NT), 0, h->stream, m, jb, P, ldp, row0,
-                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit);
+                           col0, d_ipiv, d_info, rec, far, status, dbg, (int2 *)h->moves, xcc, h->panel_xcc_word, h->panel_spin_limit, -1.0);
     LSX_HIP(hipGetLastError());
     h->moves_valid = true;
     return LSX_OK;
@@ -708,6 +749,16 @@ int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, 
     if (m <= 32 * 64 * 2) return panel_xcd_rt<T, 2>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
     if (sizeof(T) == 4 && m > 32 * 64 * 4) return panel_xcd_rt<T, sizeof(T) == 4 ? 8 : 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
     return panel_xcd_rt<T, 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info);
+}
+
+// The same panel under the reference's pivot rule (first row in the current order with |a| > tol); fp64, at most 8192
+// rows.  Returns 1 for anything else.
+int panel_xcd_first(lsx_handle_t h, int m, int jb, double *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info,
+                    double tol) {
+    if (tol < 0.0 || m > 32 * 64 * 4) return 1;
+    if (m <= 32 * 64 * 1) return panel_xcd_rt<double, 1>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info, tol);
+    if (m <= 32 * 64 * 2) return panel_xcd_rt<double, 2>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info, tol);
+    return panel_xcd_rt<double, 4>(h, m, jb, P, ldp, row0, col0, d_ipiv, d_info, tol);
 }
 
 template int panel_xcd<double>(lsx_handle_t, int, int, double *, int, int, int, int32_t *, int *);

@@ -371,6 +371,35 @@ int rref_blocked(lsx_handle_t h, int m, int n, int bar, T *W, int ldw, int32_t *
     return LSX_OK;
 }
 
+// dst[i][k] = src[i][pivots[2 k + 1]] for rows i >= row_lo: the pivot columns of a row reduction as a dense m x r block
+template <typename T>
+__global__ __launch_bounds__(256) void gather_pivot_cols_kernel(int m, int r, int row_lo, const T *__restrict__ src, int lds,
+                                                                const int32_t *__restrict__ pivots, T *__restrict__ dst, int ldd) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= r) return;
+    const int pc = pivots[2 * k + 1];
+    for (int i = row_lo + blockIdx.y; i < m; i += gridDim.y) dst[(size_t)i * ldd + k] = src[(size_t)i * lds + pc];
+}
+template <typename T>
+int launch_gather_pivot_cols(lsx_handle_t h, int m, int r, int row_lo, const T *src, int lds, const int32_t *d_pivots, T *dst,
+                             int ldd) {
+    if (r <= 0 || m <= row_lo) return LSX_OK;
+    hipLaunchKernelGGL(gather_pivot_cols_kernel<T>, dim3((r + 255) / 256, std::min(m - row_lo, 4096)), dim3(256), 0, h->stream, m, r,
+                       row_lo, src, lds, d_pivots, dst, ldd);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+// pivot columns -> exact unit vectors, rows >= rank -> exact zeros left of the bar (what the reference's arithmetic leaves)
+template <typename T>
+int launch_rref_finish(lsx_handle_t h, int m, int bar, T *W, int ldw, const int32_t *d_pivots, int rank) {
+    hipLaunchKernelGGL(rrb_finish_kernel<T>, dim3((std::max(bar, rank) + 255) / 256, std::min(m, 65535)), dim3(256), 0, h->stream, m, bar,
+                       W, ldw, d_pivots, rank);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+template int launch_gather_pivot_cols<double>(lsx_handle_t, int, int, int, const double *, int, const int32_t *, double *, int);
+template int launch_rref_finish<double>(lsx_handle_t, int, int, double *, int, const int32_t *, int);
+
 template int rref_blocked<double>(lsx_handle_t, int, int, int, double *, int, int32_t *, int *, double, int);
 template int rref_blocked<float>(lsx_handle_t, int, int, int, float *, int, int32_t *, int *, double, int);
 

@@ -375,14 +375,31 @@ class Matrix:
                 R[:, :m] = np.eye(m)
                 R[:, m:] = X
                 return R, [(k, k) for k in range(m)]
-        # rank and pivot positions from the well-conditioned rule (largest |a|) ...
+        # Large inputs: ONE call.  The blocked first-rule reduction (csrc/api.hip: rref_first_fast) takes rank and pivot
+        # columns from the rank-revealing pass and the reference's row choice (first non-zero row, linalg.py:548-552)
+        # from a blocked LU of those columns under that rule, so its result IS the reference's reduction.
+        h = dense._h(None)
+        R1, pivots1, rank1 = dense.rref(A, bar_col=bar, pivot_rule=dense.N.PIVOT_FIRST)
+        if h.get_option("rref_first_used"):
+            return R1, pivots1
+        # Small inputs (per-column kernels): rank and pivot positions from the well-conditioned rule (largest |a|) ...
         R, pivots, rank = dense.rref(A, bar_col=bar, pivot_rule=dense.N.PIVOT_MAX)
         if rank < m:
-            # ... but with rank < m the carried-along columns depend on WHICH rows became pivot
-            # rows, so reproduce the reference's choice (first non-zero row, linalg.py:548-552)
-            R1, pivots1, _ = dense.rref(A, bar_col=bar, pivot_rule=dense.N.PIVOT_FIRST)
+            # ... but with rank < m the carried-along columns depend on WHICH rows became pivot rows, so the values
+            # come from the pass under the reference's rule when the two agree on the pivots
             if pivots1 == pivots:
                 R = R1
+            else:
+                # the first-non-zero rule, run without magnitude pivoting, settled on other pivot columns than the
+                # rank-revealing pass (noise in a dependent column passed its tolerance): the rank-revealing pivots and
+                # values are returned, and the caller is TOLD that the carried-along columns are then not the
+                # reference's (this used to pass silently)
+                import warnings
+
+                warnings.warn("row_reduce: the reference's first-non-zero pivot rule and the rank-revealing pass disagree on "
+                              f"the pivot columns ({len(pivots1)} vs {len(pivots)} pivots); returning the rank-revealing "
+                              "reduction -- columns right of bar_col and rows below the rank follow its row choice, not the "
+                              "reference's", RuntimeWarning, stacklevel=3)
         return R, pivots
 
     # step descriptions of the reference's log (linalg.py:557-560, 580, 602-604, 626), verbatim: they are

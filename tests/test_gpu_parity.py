@@ -1163,6 +1163,82 @@ def test_blocked_rref_matches_the_unblocked_kernel(la, m, n, rank, bar):
     assert np.max(np.abs(A[:, pc] @ R1[:r1, :bar] - A[:, :bar])) / np.max(np.abs(A)) < 1e-9
 
 
+@pytest.mark.parametrize("m,n,rank,bar,swaps", [(300, 340, 40, 320, False), (300, 340, 40, 320, True), (520, 300, 130, 280, True),
+                                                 (260, 600, 70, 600, False)])
+def test_first_rule_blocked_reduction_matches_the_exact_reference_rule(la, m, n, rank, bar, swaps):
+    """the reference's first-non-zero pivot rule (linalg.py:548-552) WITHOUT the per-column pass --
+    pivot columns from the rank-revealing reduction, the reference's row choice from a blocked LU of those columns
+    under the first-non-zero rule, carried-along columns and rows below the rank from one solve + one MFMA update.
+    Checked against (i) the oracle's restatement of the reference run in exact rational arithmetic -- pivots equal,
+    every entry within 1e-9, including the columns right of bar_col and the rows below the rank, which are the part
+    that depends on the rule -- and (ii) the per-column kernels.  `swaps`: zero entries planted on the diagonal path so
+    that the rule has to exchange rows (and a max-rule reduction would pick different rows everywhere anyway)."""
+    from fractions import Fraction
+
+    from linalg_solver_amd import _native, dense
+
+    h = la.default_handle()
+    rng = np.random.default_rng(m * 3 + n + rank)
+    Bf = rng.integers(-2, 3, (m, rank))
+    Cf = rng.integers(-2, 3, (rank, n))
+    if swaps:
+        Bf[0, :] = 0           # row 0 of the product is zero: the very first pivot needs an interchange
+        Bf[5, :] = Bf[3, :]    # a duplicate row: becomes a zero row mid-way
+        Bf[7, :] = 0
+    Ai = Bf @ Cf
+    A = Ai.astype(np.float64)
+    try:
+        h.set_option("rref_first_fast", 1)
+        R1, piv1, r1 = dense.rref(A, bar_col=bar, pivot_rule=_native.PIVOT_FIRST)
+        used = h.get_option("rref_first_used")
+        h.set_option("rref_first_fast", 0)
+        R0, piv0, r0 = dense.rref(A, bar_col=bar, pivot_rule=_native.PIVOT_FIRST)
+    finally:
+        h.set_option("rref_first_fast", 1)
+    assert used == 1, "the blocked first-rule form did not run"
+    exact, epiv, _ = rowreduce.row_reduce([[Fraction(int(v)) for v in row] for row in Ai], bar)
+    E = np.array([[float(v) for v in row] for row in exact])
+    assert piv1 == epiv == piv0 and r1 == len(epiv)
+    scale = max(1.0, float(np.max(np.abs(E))))
+    assert np.max(np.abs(R1 - E)) / scale < 1e-9, "blocked first-rule reduction differs from the exact reference run"
+    assert np.max(np.abs(R0 - E)) / scale < 1e-9
+    pc = [c for _, c in piv1]
+    assert np.array_equal(R1[:r1][:, pc], np.eye(r1)) and not R1[r1:, :bar].any()
+
+
+def test_first_rule_reduction_at_8192_rank_4096_through_the_matrix_surface(la):
+    """The same at the size of bench.py's row-reduction line, through Matrix.row_reduce_array with bar_col < n: rank and
+    pivots as planted, the defining identities, and the rule itself -- with the first 4096 rows independent the
+    reference never exchanges rows, so the rows below the rank are (row i of A) - A[i, pc] R[:r], in the ORIGINAL row
+    order, and the top rows are spanned by the first 4096 rows of A."""
+    import torch
+
+    from linalg_solver_amd import gen
+    from linalg_solver_amd.device import DeviceSolver
+
+    dev = DeviceSolver()
+    n, rk, bar = 8192, 4096, 6000
+    B = torch.empty(n, rk, dtype=torch.float64, device="cuda")
+    C = torch.empty(rk, n - rk, dtype=torch.float64, device="cuda")
+    dev.fill_(B, gen.U11, 3)
+    dev.fill_(C, gen.U11, 4)
+    A = torch.cat([B, B @ C / 64.0], dim=1).contiguous().cpu().numpy()
+    import time
+    t0 = time.perf_counter()
+    R, piv = la.Matrix.from_numpy(A).row_reduce_array(bar_col=bar)
+    dt = time.perf_counter() - t0
+    assert la.default_handle().get_option("rref_first_used") == 1
+    print(f"Matrix.row_reduce_array 8192^2 rank 4096 bar_col {bar}: {dt:.3f} s (host arrays in and out)")
+    assert piv == [(k, k) for k in range(rk)]
+    assert np.array_equal(R[:rk, :rk], np.eye(rk)) and not R[rk:, :bar].any()
+    Cn = C.cpu().numpy() / 64.0
+    assert np.max(np.abs(R[:rk, rk:] - Cn)) < 1e-7          # carried-along columns of the pivot rows included
+    # rows below the rank, columns right of the bar: A2 - A2[:, pc] R_top with NO interchanges (first-rule semantics)
+    want = A[rk:, bar:] - A[rk:, :rk] @ R[:rk, bar:]
+    assert np.max(np.abs(R[rk:, bar:] - want)) < 1e-9 * max(1.0, np.max(np.abs(want)))
+    assert dt < 3.0
+
+
 def test_blocked_rref_8192_rank_4096(dev):
     """8192 x 8192 of rank 4096 on the device -- pivots against the planted structure (the first
     4096 columns are independent, every later column is a combination of them) and A = A[:, pc] R."""
