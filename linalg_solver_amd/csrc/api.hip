@@ -170,6 +170,11 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     // this schedule shares the CUs between the panel and the update: the XCD-scope panel (which fills an XCD) has
     // its own driver, getrf_lookahead_x; here it would stall every launch beside it
     if (h->panel_mode == 4) h->panel_mode = 3;
+    // Panels taller than one XCD holds (the phase in front of getrf_lookahead_x): 256-row slices, i.e. half as many
+    // workgroups of the device-scope panel.  Its time per column does not depend on the slicing (2.5-2.6 us, kbench
+    // panel3tall), but every CU it holds is one the update -- the bottleneck of this phase -- does not have:
+    // 16384^2 fp64 77.8 -> 74.6 ms, 12288^2 38.5 -> 37.9 ms, same bits (tools/lu_tall.py).
+    if (sizeof(T) == 8 && k_stop > 0 && h->panel_nt == 0 && n - k0 > 8192) { h->panel_nt = 512; h->panel_rt = 8; }
     // Exchange areas of the pipelined panel: two, used alternately, and cleared HERE on the main stream as
     // soon as their panel has finished -- a clear in front of every panel launch sits on the chain.
     size_t area = panel_pipe_area_bytes(h, n - k0);
@@ -298,7 +303,8 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     };
     const size_t area = panel_x_area_bytes(h, n - k0, sizeof(T));
     const size_t pass_bytes = pad256(256 + (size_t)nsteps * sizeof(int)), ctr_bytes = pad256((size_t)nsteps * 8 * sizeof(int));
-    const size_t words = pass_bytes + ctr_bytes + pad256((size_t)nsteps * 2 * sizeof(int));
+    const size_t col0_bytes = pad256((size_t)nsteps * 2 * sizeof(int));
+    const size_t words = pass_bytes + ctr_bytes + col0_bytes + pad256((size_t)nsteps * sizeof(int));
     if (area == 0 || 3 * area + words > h->scratch_bytes) { set_error("getrf_lookahead_x: scratch"); return LSX_ERR_INTERNAL; }
     LSX_TRY(grow(&h->moves_all, &h->moves_all_bytes, (size_t)nsteps * 2048));
     struct Restore {
@@ -317,6 +323,7 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     int *pass = (int *)(wbase + 256);                // per step: update workgroups that left the panel's XCD
     int *counters = (int *)(wbase + pass_bytes);     // per step: the update's eight strip queues
     int *col0 = (int *)(wbase + pass_bytes + ctr_bytes);   // per step: {ticket, finished tiles} of the update's tile column 0
+    int *ready = (int *)(wbase + pass_bytes + ctr_bytes + col0_bytes);   // per step: block inverses finished (fused chain launch)
     LSX_HIP(hipMemsetAsync(h->scratch, 0, 3 * area + words, main_s));
     LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)xcc_word, 1, 1, main_s));
     h->panel_area_stride = area;
@@ -357,6 +364,7 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         T *L21 = A + (size_t)(k + jb) * lda + k;
         T *A22 = A + (size_t)(k + jb) * lda + k + jb;
         const int jb2 = rest < nb ? rest : nb;  // width of the next panel
+        bool fused_all = false;
         {
             OnSide g(h, side);
             // update k-1 wrote the next panel's columns: its column-0 count (waited for inside the chain head), or the
@@ -365,23 +373,36 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             if (step > 0 && !counted) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
             h->moves = list(step);
             h->moves_valid = true;
-            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k,
-                                                   counted ? col0 + 2 * (step - 1) + 1 : nullptr, prev_tiles);
-            if (fused < 0) return fused;
-            if (fused == 1) {
-                if (counted) LSX_TRY(launch_wait_count(h, col0 + 2 * (step - 1) + 1, prev_tiles));
-                LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
-                LSX_TRY(launch_laswp_moves<T>(h, jb2, A + k + jb, lda, k));
+            // block inverses, interchanges and U12 of the next panel's columns in one launch where the shapes allow it
+            const int all = launch_chain_fused<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k,
+                                                  counted ? col0 + 2 * (step - 1) + 1 : nullptr, prev_tiles, ready + step);
+            if (all < 0) return all;
+            if (all == 1) {
+                const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k,
+                                                       counted ? col0 + 2 * (step - 1) + 1 : nullptr, prev_tiles);
+                if (fused < 0) return fused;
+                if (fused == 1) {
+                    if (counted) LSX_TRY(launch_wait_count(h, col0 + 2 * (step - 1) + 1, prev_tiles));
+                    LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
+                    LSX_TRY(launch_laswp_moves<T>(h, jb2, A + k + jb, lda, k));
+                }
             }
-            LSX_HIP(hipEventRecord(h->ev_panel, side));   // HEAD: block inverses of panel k are there
-            LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
+            // HEAD: block inverses of panel k are there.  The fused launch counts them in a device word the main stream
+            // waits for in a one-wave kernel: an event record here would be a marker packet BETWEEN the chain's launches
+            // (6 us on the panel-to-panel path -- what the fusion itself saved)
+            fused_all = all == LSX_OK;
+            if (!fused_all) {
+                LSX_HIP(hipEventRecord(h->ev_panel, side));
+                LSX_TRY(launch_trsm_block<T>(h, 1, jb, jb2, Akk, lda, Ti, A12, lda));
+            }
             LSX_TRY(launch_gemm_sub<T>(h, rest, jb2, jb, L21, lda, A12, lda, A22, lda));
         }
         // main stream, behind HEAD.  Measured alternatives (8192^2 / 4096^2, ms): this order 18.2 / 7.6; interchanges
         // ahead of HEAD and the area cleared by the update's idle workgroups, so that the update starts earlier,
         // 18.5 / 7.9 (its resident workgroups take the CUs the next panel's small update needs: 27 instead of 17 us);
         // the update ordered behind that small update by an event 19.0 / 8.0 (a cross-stream hop on the chain).
-        LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+        if (fused_all) LSX_TRY(launch_wait_count(h, ready + step, 2));
+        else LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
         int queued = 0;
         bool cur_col0 = false;
         int cur_tiles = 0;
@@ -990,6 +1011,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_xcd")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_xcd = value;
+    } else if (!strcmp(key, "chain_fused")) {   // 0: chain head and the next panel's block solve as separate launches (cross-check)
+        LSX_ARG(value == 0 || value == 1);
+        h->chain_fused = value;
     } else if (!strcmp(key, "rref_first_fast")) {   // 0: LSX_PIVOT_FIRST always through the per-column kernels (cross-check)
         LSX_ARG(value == 0 || value == 1);
         h->rref_first_fast = value;
@@ -1027,6 +1051,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "panel_xcd")) *value = h->panel_xcd;
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "rref_first_fast")) *value = h->rref_first_fast;
+    else if (!strcmp(key, "chain_fused")) *value = h->chain_fused;
     else if (!strcmp(key, "rref_first_used")) *value = h->rref_first_used;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "diag_panels")) {

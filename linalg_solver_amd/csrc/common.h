@@ -102,6 +102,7 @@ struct lsx_handle_s {
     int *gemm_counters = nullptr; // gemm_counter_sets x 8 ints in scratch, zeroed by the driver
     int gemm_counter_sets = 0, gemm_counter_set = 0;
     int *gemm_pass_word = nullptr;   // incremented by every workgroup that leaves because it sits on the avoided XCD
+    int chain_fused = 1;             // 1: chain head and the next panel's block solve in one launch (option chain_fused)
     int *chain_info = nullptr;       // look-ahead driver: the factorisation's info word, for the chain's in-kernel waits (time-out -> negative)
     int chain_wait_limit = 1 << 21;  // polls of those waits before they give up (option chain_wait_limit: tests inject a time-out with 0)
     int *gemm_col0 = nullptr;        // look-ahead driver: {ticket, done} words of this update's tile column 0 (zeroed by the driver)
@@ -258,6 +259,10 @@ int launch_trtri(lsx_handle_t h, int lower, int jb, const T *Tm, int ldt, T *Tin
 template <typename T>
 int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
                       const int *wait_word = nullptr, int wait_target = 0);
+// chain head + block solve of the next panel's 128 columns in one launch (kernels_misc.hip); 1 = shapes not served
+template <typename T>
+int launch_chain_fused(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                       const int *wait_word, int wait_target, int *ready);
 template <typename T>
 int launch_trtri_both(lsx_handle_t h, int n, const T *LU, int lda, T *invL, T *invU);
 // B (jb x ncols) <- inv(Tm) * B in place; Tinv = inverses of Tm's 64x64 diagonal blocks.

@@ -331,12 +331,22 @@ __device__ void lds_gemm_tile(int M, int N, int K, const T *A, int lda, const T 
 // lower = 0 / 1: that triangle; lower = 2: blockIdx.y = 0 inverts the lower, 1 the upper triangle, the
 // upper inverses going to Tinv + upper_off (both triangles of an LU in one launch)
 template <typename T>
+__device__ __forceinline__ void trtri64_work(int bx, int by, int lower, int jb, const T *__restrict__ Tm,
+                                             int ldt, T *__restrict__ Tinv, size_t upper_off, T *X, T *W);
+template <typename T>
 __device__ __forceinline__ void trtri64_body(int bx, int by, int lower, int jb, const T *__restrict__ Tm,
                                              int ldt, T *__restrict__ Tinv, size_t upper_off) {
     // 16-byte aligned: the fast paths move pairs of T, and inside the fused chain-head kernel the arrays follow
     // other LDS variables
     __shared__ __attribute__((aligned(16))) T X[TB * TLD];   // triangle in, inverse out
     __shared__ __attribute__((aligned(16))) T W[32 * TLD];   // merge temporary
+    trtri64_work<T>(bx, by, lower, jb, Tm, ldt, Tinv, upper_off, X, W);
+}
+// the same with the two LDS arrays handed in (X: TB * TLD, W: 32 * TLD elements, 16-byte aligned): the fused chain
+// kernel carves them out of its dynamic allocation, which the block-solve workgroups of the same launch use otherwise
+template <typename T>
+__device__ __forceinline__ void trtri64_work(int bx, int by, int lower, int jb, const T *__restrict__ Tm,
+                                             int ldt, T *__restrict__ Tinv, size_t upper_off, T *X, T *W) {
     if (lower == 2) {
         lower = by == 0;
         if (!lower) Tinv += upper_off;
@@ -499,6 +509,7 @@ int launch_chain_head(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int
     return LSX_OK;
 }
 
+
 // Diagnostics (tests/test_gpu_parity.py: the fused chain head against the separate launches): block inverses of
 // the unit-lower triangle at Tm through chain_head_kernel with an all-void gather list on `ncols` columns of A.
 template <typename T>
@@ -625,19 +636,27 @@ __device__ __forceinline__ void lds_gemm_regs(const T *A, int lda, const T *B, i
 }
 
 template <typename T>
+__device__ __forceinline__ void trsm_block2_body(int bx, int lower, int jb, int ncols, const T *__restrict__ Tm, int ldt,
+                                                 const T *__restrict__ Tinv, T *__restrict__ B, int ldb, char *smem);
+template <typename T>
 __global__ __launch_bounds__(256) void trsm_block2_kernel(int lower, int jb, int ncols,
                                                           const T *__restrict__ Tm, int ldt,
                                                           const T *__restrict__ Tinv, T *__restrict__ B,
                                                           int ldb) {
     LSX_TS(3);
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    trsm_block2_body<T>(blockIdx.x, lower, jb, ncols, Tm, ldt, Tinv, B, ldb, smem);
+}
+template <typename T>
+__device__ __forceinline__ void trsm_block2_body(int bx, int lower, int jb, int ncols, const T *__restrict__ Tm, int ldt,
+                                                 const T *__restrict__ Tinv, T *__restrict__ B, int ldb, char *smem) {
     constexpr int BLD = CWT + 2;
     T *Bs = (T *)smem;              // [128][BLD]
     T *T0 = Bs + 128 * BLD;         // inverse of the first diagonal block to be applied
     T *T1 = T0 + TB * TLD;          // off-diagonal block
     T *T2 = T1 + TB * TLD;          // inverse of the second diagonal block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c0 = blockIdx.x * CWT;
+    const int c0 = bx * CWT;
     // order of the two 64-row blocks: lower = (0 then 1), upper = (1 then 0)
     const int b_first = lower ? 0 : 1, b_second = lower ? 1 : 0;
     typedef T v2t __attribute__((ext_vector_type(2)));
@@ -748,6 +767,82 @@ int launch_trsm_block(lsx_handle_t h, int lower, int jb, int ncols, const T *Tm,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     hipLaunchKernelGGL(trsm_block_kernel<T>, dim3((ncols + CWT - 1) / CWT), dim3(256), shm, h->stream,
                        lower, jb, ncols, Tm, ldt, Tinv, B, ldb);
+    LSX_HIP(hipGetLastError());
+    return LSX_OK;
+}
+
+// The chain head AND the block solve of the next panel's column block in ONE launch (round 3: one launch, one event
+// and ~7 us less between two panels).  Workgroups [0, 2): the two 64 x 64 block inverses of panel k (written to Tinv
+// for the main stream's block solve, then counted in *ready behind a device-scope fence).  Workgroups [2, 6): one
+// 32-column chunk of the next panel's columns each -- panel k's interchanges on the chunk (all moved rows), then, once
+// both inverses are there, U12 of the chunk: the same three 64 x 64 x 32 MFMA products as trsm_block2_kernel, from the
+// same operands, so the bits are those of the separate launches.  Lower block indices are dispatched first, so the
+// consumers never wait for a workgroup that is not resident.  jb = ncols = 128 and the 16-byte paths only.
+template <typename T, int CW, int VW>
+__global__ __launch_bounds__(256) void chain_fused_kernel(int jb, const T *__restrict__ Tm, int ldt, T *__restrict__ Tinv,
+                                                          T *__restrict__ A, int lda, int row0,
+                                                          const int2 *__restrict__ moves, const int *wait_word, int wait_target,
+                                                          int wait_limit, int *status, int *info, int *ready) {
+    LSX_TS(2);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (wait_word) {
+        if (threadIdx.x == 0) {
+            bool ok = false;
+            for (int i = 0; i < wait_limit && !ok; ++i) {
+                ok = __hip_atomic_load(wait_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_target;
+                if (!ok) __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok && status) atomicMax(status, 1);
+            if (!ok && info && blockIdx.x == 0) atomicMin(info, -0x40000000);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        }
+        __syncthreads();
+    }
+    constexpr int NTRI = 2;
+    if ((int)blockIdx.x < NTRI) {
+        T *X = (T *)smem, *W = X + TB * TLD;
+        trtri64_work<T>(blockIdx.x, 0, 1, jb, Tm, ldt, Tinv, 0, X, W);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const int chunk = (int)blockIdx.x - NTRI;
+    laswp_moves_body<T, CW, VW>(chunk, 128 / VW, A, lda / VW, row0, moves, 0x7fffffff, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool ok = false;
+        for (int i = 0; i < (1 << 22) && !ok; ++i)
+            ok = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= NTRI;
+        if (!ok) {
+            if (status) atomicMax(status, 1);
+            if (info) atomicMin(info, -0x40000000);
+        }
+    }
+    __syncthreads();
+    // device scope: the inverses of the other workgroups, and this workgroup's own interchanged rows (written through
+    // to L2 by other threads of it; lines of those rows may sit in L1 from the gather), are read from L2
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    trsm_block2_body<T>(chunk, 1, jb, 128, Tm, ldt, Tinv, A + (size_t)row0 * lda, lda, smem);
+}
+
+// Returns 1 when the shapes do not allow it (the caller issues chain head and block solve separately).
+template <typename T>
+int launch_chain_fused(lsx_handle_t h, int jb, const T *Tm, int ldt, T *Tinv, int ncols, T *A, int lda, int row0,
+                       const int *wait_word, int wait_target, int *ready) {
+    constexpr int VW = 16 / (int)sizeof(T);
+    constexpr int CW = 32 / VW;
+    if (!h->chain_fused || !h->moves_valid || jb != 128 || ncols != 128 || ((size_t)A % 16) || lda % VW ||
+        ((size_t)Tm % 16) || ((size_t)Tinv % 16) || ldt % 2 || !ready)
+        return 1;
+    const size_t shm = ((size_t)128 * (CWT + 2) + 3 * TB * TLD) * sizeof(T);
+    ProfScope ps(h, LSX_PROF_TRSM, (double)jb * jb * ncols);
+    LSX_HIP(hipFuncSetAttribute((const void *)chain_fused_kernel<T, CW, VW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+    hipLaunchKernelGGL((chain_fused_kernel<T, CW, VW>), dim3(2 + 128 / 32), dim3(256), shm, h->stream, jb, Tm, ldt, Tinv, A, lda,
+                       row0, (const int2 *)h->moves, wait_word, wait_target, h->chain_wait_limit, h->dev_status, h->chain_info,
+                       ready);
     LSX_HIP(hipGetLastError());
     return LSX_OK;
 }
@@ -1166,6 +1261,7 @@ int launch_refine_apply(lsx_handle_t h, int n, int nrhs, int init, const float *
     template int launch_laswp_left_all<T>(lsx_handle_t, T *, int, int, int, int, const void *);   \
     template int launch_laswp_moves_around<T>(lsx_handle_t, int, T *, int, int, int, int);        \
     template int launch_chain_head<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int, const int *, int);  \
+    template int launch_chain_fused<T>(lsx_handle_t, int, const T *, int, T *, int, T *, int, int, const int *, int, int *); \
     template int launch_trtri<T>(lsx_handle_t, int, int, const T *, int, T *);                    \
     template int launch_trtri_both<T>(lsx_handle_t, int, const T *, int, T *, T *);               \
     template int launch_trsm_block<T>(lsx_handle_t, int, int, int, const T *, int, const T *, T *, \

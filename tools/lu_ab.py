@@ -1,0 +1,27 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from linalg_solver_amd import gen
+from linalg_solver_amd.device import DeviceSolver
+dev = DeviceSolver()
+for n in (8192, 4096, 12288):
+    A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    dev.fill_(A0, gen.U11, 1)
+    ref = None
+    for fused in (0, 1, 0, 1):
+        dev.h.set_option("chain_fused", fused)
+        A = A0.clone()
+        ts = []
+        for r in range(6):
+            A.copy_(A0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ipiv, info = dev.getrf_(A)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        if ref is None:
+            ref = (A.clone(), ipiv.clone())
+            same = "ref"
+        else:
+            same = "same bits" if torch.equal(A, ref[0]) and torch.equal(ipiv, ref[1]) else "MISMATCH"
+        print(f"n={n} chain_fused={fused}: {min(ts[1:]) * 1e3:.3f} ms  info={int(info.item())} {same}", flush=True)
