@@ -180,6 +180,19 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
     size_t area = panel_pipe_area_bytes(h, n - k0);
     if (2 * area > h->scratch_bytes) area = 0;
     if (area) LSX_HIP(hipMemsetAsync(h->scratch, 0, 2 * area, main_s));
+    // Counted first tile column of the big update (fp64, this driver as the phase in front of getrf_lookahead_x): the
+    // chain of step k then waits, inside its first kernel, for update k-1 on the NEXT panel's columns only and runs
+    // beside the rest of that update -- the update of step k follows update k-1 without the chain in between
+    // (16384^2: the chain was ~45 us of every one of the 64 steps of this phase).
+    const int nst = (n - k0 + nb - 1) / nb;
+    int *c0words = nullptr;
+    if (sizeof(T) == 8 && k_stop > 0 && area && 2 * area + pad256((size_t)nst * sizeof(int)) <= h->scratch_bytes && !h->x_events) {
+        c0words = (int *)((char *)h->scratch + 2 * area);
+        LSX_HIP(hipMemsetAsync(c0words, 0, (size_t)nst * sizeof(int), main_s));
+    }
+    struct ClearCol0 { lsx_handle_t h; ~ClearCol0() { h->gemm_col0_static = nullptr; } } clear_col0{h};
+    bool prev_counted = false;
+    int prev_tiles = 0;
     h->panel_area_stride = area;
     h->panel_area = 0;
     // the side stream starts after everything already queued on the main stream (info memset, fills)
@@ -240,9 +253,11 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
             h->moves = h->moves_buf[step & 1];
             // block inverses and the next block's interchanges in one launch (the main stream starts behind the
             // chain anyway: the CUs are shared)
-            if (have_update) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
-            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k);
+            if (have_update && !prev_counted) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
+            const int fused = launch_chain_head<T>(h, jb, Akk, lda, Ti, jb2, A + k + jb, lda, k,
+                                                   prev_counted ? c0words + (step - 1) : nullptr, prev_tiles);
             if (fused < 0) return fused;
+            if (fused == 1 && prev_counted) LSX_TRY(launch_wait_count(h, c0words + (step - 1), prev_tiles));
             if (fused == 1) {
                 LSX_TRY(launch_trtri<T>(h, 1, jb, Akk, lda, Ti));
                 LSX_TRY(apply_panel_swaps<T>(h, jb2, A + k + jb, lda, k, jb, d_ipiv + k));
@@ -252,12 +267,17 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
             // Sharing the CUs, the big update would take the slots these small launches need (measured:
             // the chain doubles); the main stream therefore starts behind the chain.
             LSX_HIP(hipEventRecord(h->ev_panel, side));
+            // panel k+1 writes the gather list and exchange area that step k-1 used: behind ALL of update k-1 and its
+            // left-hand interchanges (with the counted column the chain above no longer waited for them)
+            if (have_update && prev_counted) LSX_HIP(hipStreamWaitEvent(side, h->ev_next, 0));
             h->moves = h->moves_buf[(step + 1) & 1];
             h->panel_area = (step + 1) & 1;
             LSX_TRY(launch_panel<T>(h, rest, jb2, A22, lda, k + jb, d_ipiv + k + jb, d_info));
             next_valid = h->moves_valid;
         }
         LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
+        bool cur_counted = false;
+        int cur_tiles = 0;
         // panel k is done with its exchange area; panel k+2 reuses it, behind ev_next below
         if (area) LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step & 1) * area, 0, area, main_s));
         h->moves = h->moves_buf[step & 1];   // panel k's list
@@ -265,7 +285,12 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         if (rest > jb2) {
             LSX_TRY(apply_panel_swaps<T>(h, rest - jb2, A + k + jb + jb2, lda, k, jb, d_ipiv + k));
             LSX_TRY(launch_trsm_block<T>(h, 1, jb, rest - jb2, Akk, lda, Ti, A12 + jb2, lda));
-            LSX_TRY(launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda));
+            h->gemm_col0_static = c0words ? c0words + step : nullptr;
+            const int rg = launch_gemm_sub<T>(h, rest, rest - jb2, jb, L21, lda, A12 + jb2, lda, A22 + jb2, lda);
+            cur_counted = c0words && h->gemm_col0_complete;
+            cur_tiles = h->gemm_col0_tiles;
+            h->gemm_col0_static = nullptr;
+            LSX_TRY(rg);
         }
         // panel k's interchanges on the columns left of it, in the slack after the update
         LSX_TRY(apply_panel_swaps<T>(h, k, A, lda, k, jb, d_ipiv + k));
@@ -274,6 +299,8 @@ static int getrf_lookahead(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
         have_update = true;
         h->moves_valid = next_valid;
+        prev_counted = cur_counted;
+        prev_tiles = cur_tiles;
     }
     join.armed = false;   // both streams were joined by the last step
     return LSX_OK;

@@ -105,6 +105,7 @@ struct lsx_handle_s {
     int chain_fused = 1;             // 1: chain head and the next panel's block solve in one launch (option chain_fused)
     int *chain_info = nullptr;       // look-ahead driver: the factorisation's info word, for the chain's in-kernel waits (time-out -> negative)
     int chain_wait_limit = 1 << 21;  // polls of those waits before they give up (option chain_wait_limit: tests inject a time-out with 0)
+    int *gemm_col0_static = nullptr; // shared-CU look-ahead driver: finished-tile count of the static grid's first tile column (zeroed by the driver)
     int *gemm_col0 = nullptr;        // look-ahead driver: {ticket, done} words of this update's tile column 0 (zeroed by the driver)
     int gemm_col0_tiles = 0;         // set with it: tiles in that column
     int x_events = 0;                // option x_events (measurements, tests): no column-0 ordering in the XCD-scope schedule

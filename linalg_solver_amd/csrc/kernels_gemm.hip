@@ -251,7 +251,8 @@ __global__ __launch_bounds__((BM_ < 64 ? 1 : BM_ / 64) * NWN * 64, (BM_ <= 64) ?
                                                           const T *__restrict__ A, int lda,
                                                           const T *__restrict__ B, int ldb,
                                                           T *__restrict__ C, int ldc, int tiles_m,
-                                                          int tiles_n, int tm_off, int tn_off, int plus) {
+                                                          int tiles_n, int tm_off, int tn_off, int plus,
+                                                          int *__restrict__ col0_done = nullptr) {
     LSX_TS(4);
     __shared__ T As[2][BK / 2][ASlab<T, BM_>::PAIR];  // AS_AT(buf, k, m) = -A[m][k]
     __shared__ T Bs[2][BK][BN + LPAD];  // Bs[buf][k][n] permuted: n' = 16*t + c  <-  column 4*c + t
@@ -267,9 +268,25 @@ __global__ __launch_bounds__((BM_ < 64 ? 1 : BM_ / 64) * NWN * 64, (BM_ <= 64) ?
     }
     plus &= 0xff;
 
+    // col0_done != nullptr (shared-CU look-ahead driver, tall phase): tile column 0 -- the next panel's columns -- goes
+    // to the FIRST tiles_m workgroups and every finished tile of it is counted behind a device-scope fence; the panel
+    // chain waits for that count inside its first kernel instead of for this whole launch.
+    if (col0_done) {
+        if ((int)blockIdx.x < tiles_m) {
+            gemm_sub_tile<T, FULL, NWN, BM_>(M, N, K, A, lda, B, ldb, C, ldc, ((int)blockIdx.x + tm_off) * BM_, tn_off * BN, As, Bs, plus);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                __hip_atomic_fetch_add(col0_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+    }
     // ---- XCD-aware grouped tile order
+    const int first_col = col0_done ? 1 : 0;            // columns left to the grouped order
+    if (col0_done) tiles_n -= 1;
     const int nwg = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+    int bid = (int)blockIdx.x - (col0_done ? tiles_m : 0);
     {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
@@ -281,7 +298,7 @@ __global__ __launch_bounds__((BM_ < 64 ? 1 : BM_ / 64) * NWN * 64, (BM_ <= 64) ?
     const int gsize = min(tiles_m - first_m, GROUP);
     const int tile_m = first_m + (bid % per_group) % gsize;
     const int tile_n = (bid % per_group) / gsize;
-    const int m0 = (tile_m + tm_off) * BM_, n0 = (tile_n + tn_off) * BN;
+    const int m0 = (tile_m + tm_off) * BM_, n0 = (tile_n + first_col + tn_off) * BN;
     gemm_sub_tile<T, FULL, NWN, BM_>(M, N, K, A, lda, B, ldb, C, ldc, m0, n0, As, Bs, plus);
 }
 
@@ -411,11 +428,16 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
         // the 8-wave fp32 form at 3 workgroups/CU is +4 % standalone and equal over an LU, so it stays opt-in
         const int waves = h->gemm_waves ? h->gemm_waves : (sizeof(T) == 8 ? 8 : 4);
         const int fm = aligned ? m / BM : 0, fn = aligned ? n / BN : 0;  // complete tiles
+        // static grid with the counted first tile column (shared-CU look-ahead driver): only when the interior launch
+        // covers that column completely, i.e. no edge strip below touches it
+        int *col0s = (h->gemm_col0_static && !h->gemm_queue && waves == 8 && fm == tm && fm > 0 && fn > 1) ? h->gemm_col0_static : nullptr;
+        h->gemm_col0_complete = col0s != nullptr;
+        h->gemm_col0_tiles = fm;
         auto go = [&](bool full, int gm, int gn, int om, int on) {
             if (gm <= 0 || gn <= 0) return;
             const dim3 grid(gm * gn);
             if (waves == 8) {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8), col0s);
                 else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
             } else {
                 if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
