@@ -4,12 +4,14 @@ import torch
 from linalg_solver_amd import gen
 from linalg_solver_amd.device import DeviceSolver
 dev = DeviceSolver()
-for n in (8192, 4096, 12288):
+OPT = sys.argv[1] if len(sys.argv) > 1 else "chain_fused"
+VALS = [int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [0, 1]
+for n in (8192, 6144, 12288, 16384):
     A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
     dev.fill_(A0, gen.U11, 1)
     ref = None
-    for fused in (0, 1, 0, 1):
-        dev.h.set_option("chain_fused", fused)
+    for fused in (VALS[0], VALS[1], VALS[0], VALS[1]):
+        dev.h.set_option(OPT, fused)
         A = A0.clone()
         ts = []
         for r in range(6):
@@ -24,4 +26,4 @@ for n in (8192, 4096, 12288):
             same = "ref"
         else:
             same = "same bits" if torch.equal(A, ref[0]) and torch.equal(ipiv, ref[1]) else "MISMATCH"
-        print(f"n={n} chain_fused={fused}: {min(ts[1:]) * 1e3:.3f} ms  info={int(info.item())} {same}", flush=True)
+        print(f"n={n} {OPT}={fused}: {min(ts[1:]) * 1e3:.3f} ms  info={int(info.item())} {same}", flush=True)
