@@ -91,6 +91,9 @@ const char *lsx_last_error(void);
  *   "kblock"        panels per trailing update [1]
  *   "trsv"          few-right-hand-side solve: 2 = 128-row steps with helper workgroups, one preparation launch [2],
  *                   1 = one cooperative launch per direction with 64-row steps, 0 = one launch per 128-row step
+ *   "panel_col"     XCD panels of up to 4096 rows: 0 = rows distributed over the workgroups [0], 1 = columns distributed
+ *                   (an independent second implementation, slower: kept as a cross-check; "panel_col_wt" = 1 runs it
+ *                   with write-through stores, lsx_get_option "panel_col_launches" counts the panels it took)
  *   "gemm_waves", "gemm_stagger", "panel_rt", "panel_nt", "hybrid", "xrows_limit", "rref_blocked",
  *   "getri_structured"                      tuning / cross-check switches, see DESIGN.md
  *   "panel_spin_limit", "trsv_spin_limit", "chain_wait_limit"   bounded-spin limits (tests inject time-outs)

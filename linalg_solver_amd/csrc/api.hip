@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace lsx {
@@ -328,7 +330,11 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         OnSide(lsx_handle_t h_, hipStream_t s) : h(h_), keep(h_->stream) { h->stream = s; }
         ~OnSide() { h->stream = keep; }
     };
-    const size_t area = panel_x_area_bytes(h, n - k0, sizeof(T));
+    // one exchange area serves either XCD panel: the row-distributed one clears and uses its first area_x bytes, the
+    // column-distributed one needs its head (inside those bytes) cleared and the multiplier buffer behind it as it is
+    const size_t area_x = panel_x_area_bytes(h, n - k0, sizeof(T));
+    const size_t area_c = h->panel_col ? panel_c_area_bytes(h, n - k0, sizeof(T)) : 0;
+    const size_t area = area_x == 0 ? 0 : (area_c > area_x ? area_c : area_x);
     const size_t pass_bytes = pad256(256 + (size_t)nsteps * sizeof(int)), ctr_bytes = pad256((size_t)nsteps * 8 * sizeof(int));
     const size_t col0_bytes = pad256((size_t)nsteps * 2 * sizeof(int));
     const size_t words = pass_bytes + ctr_bytes + col0_bytes + pad256((size_t)nsteps * sizeof(int));
@@ -351,7 +357,13 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     int *counters = (int *)(wbase + pass_bytes);     // per step: the update's eight strip queues
     int *col0 = (int *)(wbase + pass_bytes + ctr_bytes);   // per step: {ticket, finished tiles} of the update's tile column 0
     int *ready = (int *)(wbase + pass_bytes + ctr_bytes + col0_bytes);   // per step: block inverses finished (fused chain launch)
-    LSX_HIP(hipMemsetAsync(h->scratch, 0, 3 * area + words, main_s));
+    for (int s = 0; s < 3; ++s) {
+        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)s * area, 0, area_x, main_s));
+        if (area_c && s < nsteps)   // the column-distributed kernel's flags and multiplier buffer: "unwritten"
+            LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)s * area + panel_c_ones_offset(h, sizeof(T)), 0xff,
+                                   panel_c_ones_bytes(n - k0 - s * nb, sizeof(T)), main_s));
+    }
+    LSX_HIP(hipMemsetAsync(wbase, 0, words, main_s));
     LSX_HIP(hipMemsetD32Async((hipDeviceptr_t)xcc_word, 1, 1, main_s));
     h->panel_area_stride = area;
     h->panel_xcc_word = xcc_word;
@@ -456,7 +468,10 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
         }
         // panel k is done with its exchange area and panel k+3 reuses it: cleared behind the update, off the path
         // HEAD -> update start -> panel k+1; the chain of panel k+3 waits for (a part of) update k+1, behind this
-        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step % 3) * area, 0, area, main_s));
+        LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step % 3) * area, 0, area_x, main_s));
+        if (area_c && step + 3 < nsteps)   // ... and the multiplier buffer of the column-distributed kernel back to "unwritten"
+            LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step % 3) * area + panel_c_ones_offset(h, sizeof(T)), 0xff,
+                                   panel_c_ones_bytes(n - k0 - (step + 3) * nb, sizeof(T)), main_s));
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
         {
             OnSide g(h, side);
@@ -486,7 +501,8 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
 // getrf_dev and the multi-device driver (mg.hip), so the two cannot drift apart.
 int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem) {
     LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)n / 32 + 2)) + 2 * pad256(elem * 2 * (size_t)n) +
-                                  ((size_t)n / 32 + 2) * 5248 + 8192 + 3 * panel_x_area_bytes(h, n, elem) + 16384 +
+                                  ((size_t)n / 32 + 2) * 5248 + 8192 +
+                                  3 * std::max(panel_x_area_bytes(h, n, elem), h->panel_col ? panel_c_area_bytes(h, n, elem) : (size_t)0) + 16384 +
                                   ((size_t)n / 16 + 2) * 40));
     const size_t tinv_elems = (size_t)((h->nb * h->kblock + 63) / 64) * 64 * 64;
     return grow(&h->ws2, &h->ws2_bytes, 2 * pad256(tinv_elems * elem));   // x2: the look-ahead driver alternates
@@ -1038,6 +1054,12 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_xcd")) {
         LSX_ARG(value == 0 || value == 1);
         h->panel_xcd = value;
+    } else if (!strcmp(key, "panel_col")) {   // XCD panel up to 4096 rows: 1 = columns over the workgroups (kernels_panel_c.hip; cross-check), 0 = rows
+        LSX_ARG(value == 0 || value == 1);
+        h->panel_col = value;
+    } else if (!strcmp(key, "panel_col_wt")) {   // tests: the column-distributed panel as if its workgroups were on several XCDs
+        LSX_ARG(value == 0 || value == 1);
+        h->panel_col_wt = value;
     } else if (!strcmp(key, "chain_fused")) {   // 0: chain head and the next panel's block solve as separate launches (cross-check)
         LSX_ARG(value == 0 || value == 1);
         h->chain_fused = value;
@@ -1079,6 +1101,9 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "rref_first_fast")) *value = h->rref_first_fast;
     else if (!strcmp(key, "chain_fused")) *value = h->chain_fused;
+    else if (!strcmp(key, "panel_col")) *value = h->panel_col;
+    else if (!strcmp(key, "panel_col_launches")) *value = (int)(h->panel_col_launches & 0x7fffffff);
+    else if (!strcmp(key, "panel_col_wt")) *value = h->panel_col_wt;
     else if (!strcmp(key, "rref_first_used")) *value = h->rref_first_used;
     else if (!strcmp(key, "panel_fallbacks")) *value = h->panel_fallbacks;
     else if (!strcmp(key, "diag_panels")) {
@@ -1563,7 +1588,8 @@ int lsx_panel_f64_dev(lsx_handle_t h, int m, int jb, double *dP, int ldp, int ro
                       int *d_info) {
     LSX_DEVICE_GUARD(h);
     LSX_ARG(h && m >= 1 && jb >= 1 && jb <= 256 && dP && d_ipiv && ldp >= jb);
-    LSX_TRY(ensure_scratch(h, pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 32 + 2) * 5248 + 8192));
+    LSX_TRY(ensure_scratch(h, std::max({pad256(16 * ((size_t)m / 32 + 2)) + ((size_t)m / 32 + 2) * 5248 + 8192, panel_x_area_bytes(h, m, 8) + 4096,
+                                        h->panel_col ? panel_c_area_bytes(h, m, 8) + 8192 : (size_t)0})));
     return launch_panel<double>(h, m, jb, dP, ldp, row0, d_ipiv, d_info);
 }
 int lsx_laswp_f64_dev(lsx_handle_t h, int ncols, double *dA, int lda, int row0, int jb,

@@ -102,6 +102,10 @@ struct lsx_handle_s {
     int *gemm_counters = nullptr; // gemm_counter_sets x 8 ints in scratch, zeroed by the driver
     int gemm_counter_sets = 0, gemm_counter_set = 0;
     int *gemm_pass_word = nullptr;   // incremented by every workgroup that leaves because it sits on the avoided XCD
+    long long panel_col_launches = 0;   // how many panels the column-distributed kernel took (tests: it really ran)
+    int panel_col_wt = 0;            // tests: 1 = run it as if its workgroups were on several XCDs (write-through stores)
+    int panel_col = 0;               // XCD panel up to 4096 rows: 1 = columns distributed over the workgroups (kernels_panel_c.hip: an independent
+                                     // second implementation, slower -- DESIGN 5 -- kept as a cross-check), 0 = rows (kernels_panel_x.hip)
     int chain_fused = 1;             // 1: chain head and the next panel's block solve in one launch (option chain_fused)
     int *chain_info = nullptr;       // look-ahead driver: the factorisation's info word, for the chain's in-kernel waits (time-out -> negative)
     int chain_wait_limit = 1 << 21;  // polls of those waits before they give up (option chain_wait_limit: tests inject a time-out with 0)
@@ -166,6 +170,9 @@ namespace lsx {
 
 int ensure_ws(lsx_handle_t h, size_t bytes);
 int ensure_getrf_workspace(lsx_handle_t h, int n, size_t elem);
+size_t panel_c_area_bytes(lsx_handle_t h, int m, size_t elem);   // exchange area of the column-distributed XCD panel (contains the row-distributed one's)
+size_t panel_c_ones_offset(lsx_handle_t h, size_t elem);          // where its 0xff-filled part starts ...
+size_t panel_c_ones_bytes(int m, size_t elem);                    // ... and how long it is for a panel of m rows
 // XCD-scope panel under the reference's first-non-zero pivot rule (kernels_panel_x.hip); 1 = shape not served
 int panel_xcd_first(lsx_handle_t h, int m, int jb, double *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info, double tol);
 template <typename T>

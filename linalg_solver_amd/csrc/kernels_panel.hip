@@ -167,14 +167,21 @@ template <typename T>
 int panel_xcd(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info);
 
 template <typename T>
+int panel_col(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info);
+
+template <typename T>
 int launch_panel(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int32_t *d_ipiv,
                  int *d_info) {
     if (m <= 0 || jb <= 0) return LSX_OK;
     h->moves_valid = false;
     ProfScope ps(h, LSX_PROF_PANEL, 0, 2.0 * sizeof(T) * m * (double)jb);
     // the panel's first column is global column row0 (square LU: panel starts on the diagonal)
-    if (h->panel_mode == 4) {   // XCD-scope exchange; taller panels than one XCD holds take the device-scope kernel
-        const int r = panel_xcd<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
+    if (h->panel_mode == 4) {   // one XCD; taller panels than it holds take the device-scope kernel
+        if (h->panel_col && !h->panel_debug) {   // columns distributed over the workgroups (kernels_panel_c.hip)
+            const int rc = panel_col<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);
+            if (rc != 1) return rc;
+        }
+        const int r = panel_xcd<T>(h, m, jb, P, ldp, row0, row0, d_ipiv, d_info);   // rows distributed, pivot exchange in the L2
         if (r != 1) return r;
     }
     if (h->panel_mode >= 3) {

@@ -1061,6 +1061,66 @@ def test_panel_exchange_timeout_falls_back_to_per_column_launches(la):
     assert info2 == 0 and np.array_equal(LU2, ref[0]) and h.get_option("panel_fallbacks") == before + 2
 
 
+@pytest.mark.parametrize("wt", [0, 1])
+def test_column_distributed_panel_is_a_second_implementation_with_the_same_bits(la, dev, wt):
+    """kernels_panel_c.hip (option panel_col = 1): the XCD panel cut the other way -- a workgroup owns four COLUMNS of all
+    rows, left-looking inside the panel, multipliers handed on through an all-ones-initialised buffer in the L2 -- shares no
+    exchange code with kernels_panel_x.hip and must reproduce its factors, pivots, info and gather list bit for bit:
+    ragged heights and widths, the reference's tie-rich integer distribution, a zero column (the slow path of the pivot
+    search), one to sixteen rows per lane, plain and write-through stores (wt), and whole factorisations under the
+    look-ahead driver (which hands panels above 4096 rows to the row-distributed kernel).  It is slower and off by
+    default: this test is what it is kept for."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    h = dev.h
+    shapes = [(4096, 128), (4000, 100), (2500, 128), (2049, 5), (1025, 4), (1000, 3), (384, 128), (257, 100), (129, 128),
+              (100, 17), (64, 1), (5, 5), (1, 1)]
+    try:
+        h.set_option("panel_col_wt", wt)
+        for m, jb in shapes:
+            for kind in (gen.U11, gen.INT5):
+                P0 = torch.empty(m, jb, dtype=torch.float64, device="cuda")
+                dev.fill_(P0, kind, 3)
+                if kind == gen.INT5 and m >= 100:
+                    P0[:, min(3, jb - 1)] = 0
+                outs = []
+                for pc in (0, 1):
+                    h.set_option("panel_col", pc)
+                    before = h.get_option("panel_col_launches")
+                    P = P0.clone()
+                    ipiv = torch.zeros(jb, dtype=torch.int32, device="cuda")
+                    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+                    dev.panel_(P, 0, ipiv, info)
+                    mv = torch.zeros(512, dtype=torch.int32, device="cuda")
+                    assert dev.panel_moves_(mv)
+                    torch.cuda.synchronize()
+                    assert h.get_option("panel_col_launches") - before == pc, "the wrong kernel took the panel"
+                    outs.append((P, ipiv, int(info.item()), mv))
+                assert outs[0][2] == outs[1][2], (m, jb, kind)
+                assert torch.equal(outs[0][1], outs[1][1]), (m, jb, kind)
+                assert torch.equal(outs[0][0], outs[1][0]), (m, jb, kind)
+                assert torch.equal(outs[0][3], outs[1][3]), (m, jb, kind)
+        for n, dt in ((1000, torch.float64), (2304, torch.float64), (5000, torch.float64), (3000, torch.float32)):
+            A0 = torch.empty(n, n, dtype=dt, device="cuda")
+            dev.fill_(A0, gen.U11, 77 + n)
+            res = []
+            for pc in (0, 1):
+                h.set_option("panel_col", pc)
+                before = h.get_option("panel_col_launches")
+                A = A0.clone()
+                ipiv, info = dev.getrf_(A)
+                torch.cuda.synchronize()
+                took = h.get_option("panel_col_launches") - before
+                assert (took > 0) == (pc == 1)
+                res.append((A, ipiv, int(info.item())))
+            assert res[0][2] == res[1][2] == 0 and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0]), n
+    finally:
+        h.set_option("panel_col", 0)
+        h.set_option("panel_col_wt", 0)
+
+
 def test_chain_wait_timeout_reaches_info_and_the_host_entry_point_recovers(la, dev):
     """the look-ahead chain waits INSIDE a kernel for the previous update's first tile column (bounded
     spin).  A time-out there used to set only the status word and go on with stale columns: the device entry point
