@@ -23,7 +23,10 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -- python3 $R/tools/kbench.py pmc > $O/pmc_w.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_h -- python3 $R/tools/kbench.py pmc > $O/pmc_h.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum --kernel-trace --output-format csv -d $O/pmc_d -- python3 $R/tools/kbench.py pmc > $O/pmc_d.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_m1 -- python3 $R/tools/kbench.py pmc > $O/pmc_m1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 --kernel-trace --output-format csv -d $O/pmc_m2 -- python3 $R/tools/kbench.py pmc > $O/pmc_m2.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcp_f -- python3 $R/tools/kbench.py pmcpanel > $O/pmcp_f.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcp_w -- python3 $R/tools/kbench.py pmcpanel > $O/pmcp_w.log 2>&1
 cd $R
+python tools/pmc_mfma_summary.py $O/pmc_m1 $O/pmc_m2 $O/r03_pmc_gemm_mfma.json || true
 find gpurun_out/ev3 -name "*.csv" | head -40
