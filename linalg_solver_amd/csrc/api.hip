@@ -603,33 +603,87 @@ static int getrf_dev(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ipiv, int 
     return LSX_OK;
 }
 
+// Block substitution sweeps shared by the multi-right-hand-side solve and the inverse: 128-row diagonal blocks (their
+// inverses in TinvL / TinvU), the rows beyond a block updated on the MFMA tile.
+// pairs: TWO blocks per trailing update -- the update of the rows beyond the pair has depth 256 (the tile then runs at 0.76 of
+// the MFMA pipe instead of 0.68, profiles/r03_pmc_gemm_mfma.json, and there are half as many launches), the block row in
+// between gets its own 128-deep update first.  Per element the same fused multiply-adds in the same order as one block at a
+// time: the accumulators start from C and take k in sequence either way; going upwards, where the block that comes second
+// in memory must be applied first, the tile rotates its k index (gemm_kshift).  Same bits (tools/getri_ab.py, tests).
+// tri (forward sweep of the inverse): block row kb only has columns [0, kb + jb) to work on, the others are exact zeros.
+template <typename T>
+static int sweep_forward(lsx_handle_t h, int n, int ncols, bool tri, bool pairs, const T *LU, int lda, const T *TinvL, T *X, int ldx) {
+    const int sb = 128;
+    auto Lp = [&](int r, int c) { return LU + (size_t)r * lda + c; };
+    auto Xp = [&](int r) { return X + (size_t)r * ldx; };
+    for (int kb = 0; kb < n;) {
+        const int jb = (n - kb < sb) ? n - kb : sb;
+        const int nc = tri ? kb + jb : ncols;
+        LSX_TRY(launch_trsm_block<T>(h, 1, jb, nc, Lp(kb, kb), lda, TinvL + (size_t)(kb / 64) * 4096, Xp(kb), ldx));
+        const int below = n - kb - jb;
+        if (below <= 0) break;
+        if (!pairs || jb != sb) {
+            LSX_TRY(launch_gemm_sub<T>(h, below, nc, jb, Lp(kb + jb, kb), lda, Xp(kb), ldx, Xp(kb + jb), ldx));
+            kb += jb;
+            continue;
+        }
+        const int jb2 = below < sb ? below : sb, nc2 = tri ? nc + jb2 : ncols;
+        LSX_TRY(launch_gemm_sub<T>(h, jb2, nc, sb, Lp(kb + sb, kb), lda, Xp(kb), ldx, Xp(kb + sb), ldx));
+        LSX_TRY(launch_trsm_block<T>(h, 1, jb2, nc2, Lp(kb + sb, kb + sb), lda, TinvL + (size_t)((kb + sb) / 64) * 4096, Xp(kb + sb), ldx));
+        if (below > jb2)   // (tri: the first block's columns nc .. nc2 - 1 are exact zeros)
+            LSX_TRY(launch_gemm_sub<T>(h, below - jb2, nc2, sb + jb2, Lp(kb + sb + jb2, kb), lda, Xp(kb), ldx, Xp(kb + sb + jb2), ldx));
+        kb += sb + jb2;
+    }
+    return LSX_OK;
+}
+
+template <typename T>
+static int sweep_backward(lsx_handle_t h, int n, int ncols, bool pairs, const T *LU, int lda, const T *TinvU, T *X, int ldx) {
+    const int sb = 128;
+    auto Up = [&](int r, int c) { return LU + (size_t)r * lda + c; };
+    auto Xp = [&](int r) { return X + (size_t)r * ldx; };
+    for (int kb = ((n - 1) / sb) * sb; kb >= 0;) {
+        const int jb = (n - kb < sb) ? n - kb : sb;
+        LSX_TRY(launch_trsm_block<T>(h, 0, jb, ncols, Up(kb, kb), lda, TinvU + (size_t)(kb / 64) * 4096, Xp(kb), ldx));
+        if (kb == 0) break;
+        const int lo = kb - sb;
+        if (!pairs || jb % 16 != 0) {
+            LSX_TRY(launch_gemm_sub<T>(h, kb, ncols, jb, Up(0, kb), lda, Xp(kb), ldx, X, ldx));
+            kb -= sb;
+            continue;
+        }
+        LSX_TRY(launch_gemm_sub<T>(h, sb, ncols, jb, Up(lo, kb), lda, Xp(kb), ldx, Xp(lo), ldx));   // the block row above only
+        LSX_TRY(launch_trsm_block<T>(h, 0, sb, ncols, Up(lo, lo), lda, TinvU + (size_t)(lo / 64) * 4096, Xp(lo), ldx));
+        if (lo > 0) {
+            // rows above the pair: k runs over block kb first, then block lo -- the order of one block at a time
+            h->gemm_kshift = sb;
+            const int rc = launch_gemm_sub<T>(h, lo, ncols, sb + jb, Up(0, lo), lda, Xp(lo), ldx, X, ldx);
+            h->gemm_kshift = 0;
+            LSX_TRY(rc);
+        }
+        kb = lo - sb;
+    }
+    return LSX_OK;
+}
+
+// two blocks per update pay where the updates are large and regular (8192^2 inverse 17.8 -> 15.7 ms, 4096^2 3.18 -> 3.05;
+// ragged or small orders lose 3-12 % to the extra launches and the edge kernels)
+static bool sweep_pairs(lsx_handle_t h, int n, int ncols) {
+    return h->getri_pairs && !h->gemm_queue && ncols >= 1024 && (n >= 7168 || (n % 128 == 0 && n >= 4096));
+}
+
 // X <- U^-1 L^-1 X for X already row-permuted (n x nrhs)
 template <typename T>
 static int lu_solve_permuted(lsx_handle_t h, int n, int nrhs, const T *LU, int lda, T *X, int ldx) {
-    const int sb = 128;
     const size_t blk = (size_t)((n + 63) / 64) * 64 * 64;
     LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(blk * sizeof(T))));
     T *TinvL = (T *)h->ws2;
     T *TinvU = (T *)((char *)h->ws2 + pad256(blk * sizeof(T)));
     LSX_TRY(launch_trtri<T>(h, 1, n, LU, lda, TinvL));
     LSX_TRY(launch_trtri<T>(h, 0, n, LU, lda, TinvU));
-    for (int kb = 0; kb < n; kb += sb) {  // forward: L y = P b   (linalg.py:587-596)
-        const int jb = (n - kb < sb) ? n - kb : sb;
-        LSX_TRY(launch_trsm_block<T>(h, 1, jb, nrhs, LU + (size_t)kb * lda + kb, lda,
-                                     TinvL + (size_t)(kb / 64) * 4096, X + (size_t)kb * ldx, ldx));
-        const int below = n - kb - jb;
-        if (below > 0)
-            LSX_TRY(launch_gemm_sub<T>(h, below, nrhs, jb, LU + (size_t)(kb + jb) * lda + kb, lda,
-                                       X + (size_t)kb * ldx, ldx, X + (size_t)(kb + jb) * ldx, ldx));
-    }
-    const int last = ((n - 1) / sb) * sb;
-    for (int kb = last; kb >= 0; kb -= sb) {  // backward: U x = y   (linalg.py:611-621)
-        const int jb = (n - kb < sb) ? n - kb : sb;
-        LSX_TRY(launch_trsm_block<T>(h, 0, jb, nrhs, LU + (size_t)kb * lda + kb, lda,
-                                     TinvU + (size_t)(kb / 64) * 4096, X + (size_t)kb * ldx, ldx));
-        if (kb > 0)
-            LSX_TRY(launch_gemm_sub<T>(h, kb, nrhs, jb, LU + kb, lda, X + (size_t)kb * ldx, ldx, X, ldx));
-    }
+    const bool pairs = sweep_pairs(h, n, nrhs);
+    LSX_TRY(sweep_forward<T>(h, n, nrhs, false, pairs, LU, lda, TinvL, X, ldx));    // L y = P b   (linalg.py:587-596)
+    LSX_TRY(sweep_backward<T>(h, n, nrhs, pairs, LU, lda, TinvU, X, ldx));          // U x = y     (linalg.py:611-621)
     return LSX_OK;
 }
 
@@ -695,30 +749,15 @@ static int getri_dev(lsx_handle_t h, int n, const T *LU, int lda, const int32_t 
         LSX_TRY(grow(&h->ws5, &h->ws5_bytes, sizeof(T) * (size_t)n * ldw));
         T *W = (T *)h->ws5;
         LSX_TRY(launch_set_identity_perm<T>(h, n, nullptr, W, ldw));
-        const int sb = 128;
         const size_t blk = (size_t)((n + 63) / 64) * 64 * 64;
         LSX_TRY(grow(&h->ws2, &h->ws2_bytes, 2 * pad256(blk * sizeof(T))));
         T *TinvL = (T *)h->ws2;
         T *TinvU = (T *)((char *)h->ws2 + pad256(blk * sizeof(T)));
         LSX_TRY(launch_trtri<T>(h, 1, n, LU, lda, TinvL));
         LSX_TRY(launch_trtri<T>(h, 0, n, LU, lda, TinvU));
-        for (int kb = 0; kb < n; kb += sb) {   // forward: L Y = I on the columns that can be non-zero
-            const int jb = (n - kb < sb) ? n - kb : sb;
-            const int nc = kb + jb;
-            LSX_TRY(launch_trsm_block<T>(h, 1, jb, nc, LU + (size_t)kb * lda + kb, lda, TinvL + (size_t)(kb / 64) * 4096,
-                                         W + (size_t)kb * ldw, ldw));
-            const int below = n - kb - jb;
-            if (below > 0)
-                LSX_TRY(launch_gemm_sub<T>(h, below, nc, jb, LU + (size_t)(kb + jb) * lda + kb, lda, W + (size_t)kb * ldw, ldw,
-                                           W + (size_t)(kb + jb) * ldw, ldw));
-        }
-        const int last = ((n - 1) / sb) * sb;
-        for (int kb = last; kb >= 0; kb -= sb) {   // backward: U Z = Y, all columns
-            const int jb = (n - kb < sb) ? n - kb : sb;
-            LSX_TRY(launch_trsm_block<T>(h, 0, jb, n, LU + (size_t)kb * lda + kb, lda, TinvU + (size_t)(kb / 64) * 4096,
-                                         W + (size_t)kb * ldw, ldw));
-            if (kb > 0) LSX_TRY(launch_gemm_sub<T>(h, kb, n, jb, LU + kb, lda, W + (size_t)kb * ldw, ldw, W, ldw));
-        }
+        const bool pairs = sweep_pairs(h, n, n);
+        LSX_TRY(sweep_forward<T>(h, n, n, true, pairs, LU, lda, TinvL, W, ldw));    // L Y = I on the columns that can be non-zero
+        LSX_TRY(sweep_backward<T>(h, n, n, pairs, LU, lda, TinvU, W, ldw));         // U Z = Y, all columns
         return launch_scatter_cols<T>(h, n, perm, W, ldw, Inv, ldi);   // Inv[:, perm[c]] = Z[:, c]
     }
     LSX_TRY(launch_set_identity_perm<T>(h, n, perm, Inv, ldi));  // P * I
@@ -1060,6 +1099,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "panel_col_wt")) {   // tests: the column-distributed panel as if its workgroups were on several XCDs
         LSX_ARG(value == 0 || value == 1);
         h->panel_col_wt = value;
+    } else if (!strcmp(key, "getri_pairs")) {   // 0: the inverse with one 128-row block per trailing update (cross-check: same bits)
+        LSX_ARG(value == 0 || value == 1);
+        h->getri_pairs = value;
     } else if (!strcmp(key, "chain_fused")) {   // 0: chain head and the next panel's block solve as separate launches (cross-check)
         LSX_ARG(value == 0 || value == 1);
         h->chain_fused = value;
@@ -1101,6 +1143,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "rref_first_fast")) *value = h->rref_first_fast;
     else if (!strcmp(key, "chain_fused")) *value = h->chain_fused;
+    else if (!strcmp(key, "getri_pairs")) *value = h->getri_pairs;
     else if (!strcmp(key, "panel_col")) *value = h->panel_col;
     else if (!strcmp(key, "panel_col_launches")) *value = (int)(h->panel_col_launches & 0x7fffffff);
     else if (!strcmp(key, "panel_col_wt")) *value = h->panel_col_wt;

@@ -90,6 +90,12 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // plus bits 16..27: the k index runs kshift, ..., K - 1, 0, ..., kshift - 1 instead of 0 ... K - 1 (a multiple of BK when
+    // FULL).  One update of depth K then has the bits of two consecutive updates whose SECOND operand block comes first in
+    // memory (block back-substitution upwards: api.hip, getri_dev).
+    const int kshift = (plus >> 16) & 0xfff;
+    plus &= 0xff;
+    auto kmap = [&](int k) { const int s = k + kshift; return s >= K ? s - K : s; };
     const int wm = (wave / NWN) * WM, wn = (wave % NWN) * WN;
     const int lc = lane & 15, lq = lane >> 4;
 
@@ -109,8 +115,8 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
     auto load_slab = [&](int k0, T (&ra)[NLA][2], T (&rb)[NL][2]) __attribute__((always_inline)) {
         if (FULL) {
             // uniform 64-bit base + 32-bit lane offset: the addresses cost NL VGPRs per operand, not 2*NL per set
-            const T *Au = A + (size_t)m0 * lda + k0;
-            const T *Bu = B + (size_t)k0 * ldb + n0;
+            const T *Au = A + (size_t)m0 * lda + kmap(k0);
+            const T *Bu = B + (size_t)kmap(k0) * ldb + n0;
 #pragma unroll
             for (int i = 0; i < NLA; ++i) {
                 const v2 v = *(const v2 *)(Au + a_off[i]);
@@ -126,15 +132,15 @@ __device__ __forceinline__ void gemm_sub_tile(int M, int N, int K, const T *__re
             for (int i = 0; i < NLA; ++i) {
                 const int row = m0 + a_row + (NT / 8) * i;
                 const int kk = k0 + a_k;
-                const T *p = A + (size_t)row * lda + kk;
-                ra[i][0] = (row < M && kk < K) ? p[0] : T(0);
-                ra[i][1] = (row < M && kk + 1 < K) ? p[1] : T(0);
+                const T *p = A + (size_t)row * lda;
+                ra[i][0] = (row < M && kk < K) ? p[kmap(kk)] : T(0);
+                ra[i][1] = (row < M && kk + 1 < K) ? p[kmap(kk + 1)] : T(0);
             }
 #pragma unroll
             for (int i = 0; i < NL; ++i) {
                 const int kk = k0 + b_k + (NT / 64) * i;
                 const int col = n0 + b_n;
-                const T *p = B + (size_t)kk * ldb + col;
+                const T *p = B + (size_t)(kk < K ? kmap(kk) : 0) * ldb + col;
                 rb[i][0] = (kk < K && col < N) ? p[0] : T(0);
                 rb[i][1] = (kk < K && col + 1 < N) ? p[1] : T(0);
             }
@@ -262,11 +268,11 @@ __global__ __launch_bounds__((BM_ < 64 ? 1 : BM_ / 64) * NWN * 64, (BM_ <= 64) ?
     // step.  Delaying the second resident wave of the grid by a fraction of a tile de-phases them;
     // measured gain 2-4 % at K = 128, inside run-to-run noise, so it is off by default.
     {
-        const int stagger = plus >> 8;
+        const int stagger = (plus >> 8) & 0xff;
         if (stagger > 0 && ((blockIdx.x >> 8) & 1))
             for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
-    plus &= 0xff;
+    plus &= ~0xff00;   // (bits 16..27, the k rotation, go on to the tile)
 
     // col0_done != nullptr (shared-CU look-ahead driver, tall phase): tile column 0 -- the next panel's columns -- goes
     // to the FIRST tiles_m workgroups and every finished tile of it is counted behind a device-scope fence; the panel
@@ -409,7 +415,11 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
     if (m <= 0 || n <= 0 || k <= 0) return LSX_OK;
     h->gemm_queue_used = 0;
     h->gemm_col0_complete = false;
-    const bool skinny = n < 16 && !h->gemm_mfma_only;
+    const bool skinny = n < 16 && !h->gemm_mfma_only && !h->gemm_kshift;
+    if (h->gemm_kshift && (h->gemm_queue || h->gemm_kshift >= k || h->gemm_kshift > 0xfff || h->gemm_kshift % BK || (k - h->gemm_kshift) % BK)) {
+        set_error("gemm: k rotation %d not served here (k = %d)", h->gemm_kshift, k);
+        return LSX_ERR_INTERNAL;
+    }
     const bool tiles64 = !h->gemm_queue && n >= 16 && sizeof(T) == 8 && (h->gemm_waves == 0 || h->gemm_waves == 8) && m % 64 == 0 &&
                          n % BN == 0 && k % BK == 0 && ((m + BM - 1) / BM) * (n / BN) <= h->num_cu / 2 &&
                          ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && ((size_t)C % 16 == 0) && lda % 2 == 0 &&
@@ -437,11 +447,11 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
             if (gm <= 0 || gn <= 0) return;
             const dim3 grid(gm * gn);
             if (waves == 8) {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8), col0s);
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8) | (h->gemm_kshift << 16), col0s);
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 4, false>), grid, dim3(512), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8) | (h->gemm_kshift << 16));
             } else {
-                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
-                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8));
+                if (full) hipLaunchKernelGGL((gemm_sub_kernel<T, 2, true>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8) | (h->gemm_kshift << 16));
+                else hipLaunchKernelGGL((gemm_sub_kernel<T, 2, false>), grid, dim3(256), 0, h->stream, m, n, k, A, lda, B, ldb, C, ldc, gm, gn, om, on, plus | (h->gemm_stagger << 8) | (h->gemm_kshift << 16));
             }
         };
         // skinny updates (the next panel's column block in the look-ahead driver, block rows in the sharded
@@ -449,10 +459,10 @@ int launch_gemm_acc(lsx_handle_t h, int plus, int m, int n, int k, const T *A, i
         if (tiles64) {
             if (m % 32 == 0 && (m / 32) * tn <= h->num_cu && !h->gemm_no_tiles32)   // even skinnier: one 32-row tile per CU
                 hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 32>), dim3((m / 32) * tn), dim3(256), 0, h->stream, m, n, k,
-                                   A, lda, B, ldb, C, ldc, m / 32, tn, 0, 0, plus);
+                                   A, lda, B, ldb, C, ldc, m / 32, tn, 0, 0, plus | (h->gemm_kshift << 16));
             else
                 hipLaunchKernelGGL((gemm_sub_kernel<T, 4, true, 64>), dim3((m / 64) * tn), dim3(256), 0, h->stream, m, n, k,
-                                   A, lda, B, ldb, C, ldc, m / 64, tn, 0, 0, plus);
+                                   A, lda, B, ldb, C, ldc, m / 64, tn, 0, 0, plus | (h->gemm_kshift << 16));
             LSX_HIP(hipGetLastError());
             return LSX_OK;
         }

@@ -23,15 +23,19 @@
 //     entries into LDS (1 barrier); l from Lbuf (L2), a[:, c] -= l * u[c] for its columns.  Lbuf is handed over filled
 //     with all-ones words (a NaN nothing computes) and a value counts as soon as it is not that: nobody waits for the
 //     acknowledgement of a store.  The multipliers of column j + 1 and the poll for it travel while column j is applied.
-//   Why four waves and not sixteen: the per-column steps that do not shrink with the row count (two arg-max reductions, the
-//     reciprocal, bookkeeping) are ~100 dependent instructions every wave executes; with four waves on a SIMD each of them
-//     costs 16 cycles of that SIMD, with one it costs 4 (measured: 1.1 us per own column at 16 waves whatever the height).
+//   Four waves (one per SIMD), up to 16 rows per lane.  The per-column steps that do not shrink with the row count (two arg-max
+//     reductions, record exchange, reciprocal, bookkeeping) are a dependent chain of ~2000 cycles whatever the number of
+//     waves (measured with 16 waves x 8 rows and with 4 x 16: 1.1 and 0.95 us per own column at 256 rows); four waves keep
+//     the barrier and the second reduction small.
 //   A row that becomes a pivot is final: its thread writes it to its LAPACK position (row j of the panel) there and then and
 //     zeroes its registers, so that no later step needs a "this row is done" mask -- a zero never wins the search (a column
 //     whose largest entry is zero takes a slow path with the mask), its multiplier is 0 x 1/pivot = 0 and the update leaves
 //     it alone.
-// Above 4096 rows the row work of a column (m multiplications, m stores through one CU's 64 bytes a cycle) outweighs the
-// saved exchange, and the row-distributed kernel takes the panel.
+// MEASURED SLOWER than kernels_panel_x.hip at every height (1.28 us per column at 256 rows, 3.1 at 4096, against 1.27 and
+// 1.47; DESIGN 5 has the stamps): the second arg-max and the barrier cost what the all-gather cost, and the row work of a column
+// (m multiplications, m stores through one CU's 64 bytes a cycle) is done by one CU instead of 32.  Off by default (option
+// panel_col); kept as an independent second implementation that must reproduce the other's bits (tests).  Above 4096 rows
+// the row-distributed kernel takes the panel.
 // Placement as in kernels_panel_x.hip: 8 G workgroups are launched, those with blockIdx % 8 == 0 take part, the XCC ids are
 // compared in a handshake and a panel whose participants do not share one runs with write-through stores.
 // Bookkeeping (LAPACK-order positions, ipiv, info, the gather list for the columns outside the panel) is the one of
@@ -536,7 +540,6 @@ size_t panel_c_area_bytes(lsx_handle_t h, int m, size_t elem) {
     const size_t off = panel_c_ones_offset(h, elem);
     return off == 0 ? 0 : (off + panel_c_ones_bytes(m, elem) + 255) & ~(size_t)255;
 }
-int panel_c_max_rows() { return PC_MAXROWS; }
 
 template <typename T, int RTC>
 static int panel_col_rt(lsx_handle_t h, int m, int jb, T *P, int ldp, int row0, int col0, int32_t *d_ipiv, int *d_info) {

@@ -1061,6 +1061,42 @@ def test_panel_exchange_timeout_falls_back_to_per_column_launches(la):
     assert info2 == 0 and np.array_equal(LU2, ref[0]) and h.get_option("panel_fallbacks") == before + 2
 
 
+@pytest.mark.parametrize("n,dt", [(4096, "f64"), (7200, "f64"), (4096, "f32")])
+def test_two_blocks_per_update_in_the_block_sweeps_keep_the_bits(la, dev, n, dt):
+    """Inverse and many-right-hand-side solve at orders where the block substitution takes TWO 128-row blocks per
+    trailing update (depth 256; going upwards the MFMA tile rotates its k index so that the block applied first is the
+    one that comes second in memory): every entry has the bits of one block at a time (option getri_pairs = 0), also at
+    a ragged order (edge kernels, a last block of 32 rows), and the inverse is one."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    h = dev.h
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    A = torch.empty(n, n, dtype=tdt, device="cuda")
+    dev.fill_(A, gen.U11, 11)
+    A0 = A.clone()
+    ipiv, info = dev.getrf_(A)
+    B0 = torch.empty(n, 1536, dtype=tdt, device="cuda")
+    dev.fill_(B0, gen.U11, 12)
+    outs = []
+    try:
+        for pairs in (0, 1):
+            h.set_option("getri_pairs", pairs)
+            inv = dev.getri(A, ipiv)
+            X = B0.clone()
+            dev.getrs_(A, ipiv, X)
+            torch.cuda.synchronize()
+            outs.append((inv, X))
+    finally:
+        h.set_option("getri_pairs", 1)
+    assert int(info.item()) == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    tol = 1e-9 if dt == "f64" else 5e-2
+    assert float((A0 @ outs[1][0] - torch.eye(n, dtype=tdt, device="cuda")).abs().max()) < tol
+    assert float((A0 @ outs[1][1] - B0).abs().max()) < tol * 10
+
+
 @pytest.mark.parametrize("wt", [0, 1])
 def test_column_distributed_panel_is_a_second_implementation_with_the_same_bits(la, dev, wt):
     """kernels_panel_c.hip (option panel_col = 1): the XCD panel cut the other way -- a workgroup owns four COLUMNS of all
