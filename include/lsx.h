@@ -91,6 +91,8 @@ const char *lsx_last_error(void);
  *   "kblock"        panels per trailing update [1]
  *   "trsv"          few-right-hand-side solve: 2 = 128-row steps with helper workgroups, one preparation launch [2],
  *                   1 = one cooperative launch per direction with 64-row steps, 0 = one launch per 128-row step
+ *   "left_per_step" look-ahead driver: a panel's interchanges on the columns left of it trail its step [1]; 0 = all panels'
+ *                   in one launch at the end
  *   "getri_pairs"   inverse / many-right-hand-side solve at large regular orders: 1 = two 128-row blocks per trailing
  *                   update (depth 256, same bits, 8192^2 inverse 17.6 -> 15.8 ms) [1], 0 = one
  *   "panel_col"     XCD panels of up to 4096 rows: 0 = rows distributed over the workgroups [0], 1 = columns distributed

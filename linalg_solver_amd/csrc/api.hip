@@ -393,6 +393,7 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     bool prev_col0 = false;
     int prev_tiles = 0;
     int step = 0;
+    int left_done = 0;   // panels [0, left_done) have had their interchanges applied to the columns left of them
     for (int k = k0; k < n; k += nb, ++step) {
         const int jb = (n - k < nb) ? n - k : nb;
         const int rest = n - k - jb;
@@ -473,6 +474,24 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
             LSX_HIP(hipMemsetAsync((char *)h->scratch + (size_t)(step % 3) * area + panel_c_ones_offset(h, sizeof(T)), 0xff,
                                    panel_c_ones_bytes(n - k0 - (step + 3) * nb, sizeof(T)), main_s));
         LSX_HIP(hipEventRecord(h->ev_next, main_s));
+        // panel k's interchanges on the columns LEFT of it: behind the update, where this stream only waits for the next
+        // HEAD (one launch for all panels at the very end was 0.3 ms of an 8192^2 factorisation, on the critical path).
+        // Its eighth of workgroups dealt to a busy panel XCD finishes when that panel does -- just before HEAD arrives.
+        // Not in update-bound steps with a wide left-hand side, where this stream IS the critical path and the launch is not
+        // small (16384^2: 8192+ columns from the first step of this driver, +0.4 ms): theirs are caught up in one launch at the
+        // first step that has room.
+        if (h->left_per_step && (rest <= 5632 || k <= 4096)) {
+            if (left_done < step) {
+                LSX_TRY(launch_laswp_left_all<T>(h, A, lda, k0 + left_done * nb, nb, step - left_done, list(left_done)));
+                left_done = step;
+            }
+            if (k > 0) {
+                h->moves = list(step);
+                h->moves_valid = true;
+                LSX_TRY(launch_laswp_moves<T>(h, k, A, lda, k));
+            }
+            left_done = step + 1;
+        }
         {
             OnSide g(h, side);
             // The gate (panel k+1 not before update k has started) is still wanted while the panel takes nearly every
@@ -493,7 +512,8 @@ static int getrf_lookahead_x(lsx_handle_t h, int n, T *A, int lda, int32_t *d_ip
     LSX_HIP(hipEventRecord(h->ev_panel, side));
     LSX_HIP(hipStreamWaitEvent(main_s, h->ev_panel, 0));
     join.armed = false;   // joined just above
-    return launch_laswp_left_all<T>(h, A, lda, k0, nb, nsteps, h->moves_all);
+    // what has not trailed its step: the last panel's (all of them with left_per_step = 0)
+    return launch_laswp_left_all<T>(h, A, lda, k0 + left_done * nb, nb, nsteps - left_done, list(left_done));
 }
 
 // Workspaces of one factorisation of order n: scratch (panel partials, gather lists, three XCD-scope exchange areas
@@ -1102,6 +1122,9 @@ int lsx_set_option(lsx_handle_t h, const char *key, int value) {
     } else if (!strcmp(key, "getri_pairs")) {   // 0: the inverse with one 128-row block per trailing update (cross-check: same bits)
         LSX_ARG(value == 0 || value == 1);
         h->getri_pairs = value;
+    } else if (!strcmp(key, "left_per_step")) {   // 0: every panel's interchanges on the columns left of it in one launch at the end (cross-check)
+        LSX_ARG(value == 0 || value == 1);
+        h->left_per_step = value;
     } else if (!strcmp(key, "chain_fused")) {   // 0: chain head and the next panel's block solve as separate launches (cross-check)
         LSX_ARG(value == 0 || value == 1);
         h->chain_fused = value;
@@ -1143,6 +1166,7 @@ int lsx_get_option(lsx_handle_t h, const char *key, int *value) {
     else if (!strcmp(key, "chain_wait_limit")) *value = h->chain_wait_limit;
     else if (!strcmp(key, "rref_first_fast")) *value = h->rref_first_fast;
     else if (!strcmp(key, "chain_fused")) *value = h->chain_fused;
+    else if (!strcmp(key, "left_per_step")) *value = h->left_per_step;
     else if (!strcmp(key, "getri_pairs")) *value = h->getri_pairs;
     else if (!strcmp(key, "panel_col")) *value = h->panel_col;
     else if (!strcmp(key, "panel_col_launches")) *value = (int)(h->panel_col_launches & 0x7fffffff);

@@ -108,6 +108,7 @@ struct lsx_handle_s {
                                      // second implementation, slower -- DESIGN 5 -- kept as a cross-check), 0 = rows (kernels_panel_x.hip)
     int gemm_kshift = 0;             // next gemm launches: the k index starts at this offset and wraps (getri_dev)
     int getri_pairs = 1;             // inverse: two 128-row blocks per trailing update (K = 256), same bits
+    int left_per_step = 1;           // XCD look-ahead driver: a panel's interchanges left of it trail its step (0: all at the end)
     int chain_fused = 1;             // 1: chain head and the next panel's block solve in one launch (option chain_fused)
     int *chain_info = nullptr;       // look-ahead driver: the factorisation's info word, for the chain's in-kernel waits (time-out -> negative)
     int chain_wait_limit = 1 << 21;  // polls of those waits before they give up (option chain_wait_limit: tests inject a time-out with 0)
