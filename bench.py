@@ -439,6 +439,15 @@ def main():
         pmc_ratio, pmc_src = cand[0]["ratio"], os.path.relpath(f, ROOT) + f" (m=n={cand[0]['m']}, k={cand[0]['k']})"
     except Exception:
         pass
+    mfma_pmc = None   # MFMA utilisation of the update from the committed counter passes (tools/pmc_mfma_summary.py)
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gemm_mfma.json")))[-1]
+        l0 = [l for l in json.load(open(f))["launches"] if l["k"] == nb * dev.h.get_option("kblock")][0]
+        mfma_pmc = {"mfma_util": l0["mfma_util"], "shader_clock_ghz": l0["shader_clock_ghz_under_profiler"],
+                    "source": os.path.relpath(f, ROOT) + f" (static grid alone, m=n={l0['m']}, k={l0['k']}; SQ_VALU_MFMA_BUSY_CYCLES / "
+                                                          "(GRBM_GUI_ACTIVE per XCD x 1024 SIMDs))"}
+    except Exception:
+        pass
     sustained = None
     if world == 1 and not args.no_extras:
         sustained = dev.h.mfma_peak(args.dtype == "f32", 100000, 1)[0]
@@ -508,6 +517,7 @@ def main():
                                              f"{pmc_src}") if pmc_ratio else "no PMC pass available",
                             "algorithmic_bytes_per_launch": g["bytes"] / max(g["launches"], 1),
                             "mfma_sustained_tflops_microbench": sustained,
+                            "mfma_util_pmc": mfma_pmc,
                             "launches": g["launches"], "avg_launch_ms": g["ms"] / max(g["launches"], 1),
                             "note": "extra untimed pass of the same look-ahead driver with only these launches bracketed"},
         "phases_ms_per_step": {k: v["ms"] for k, v in phases.items()},
