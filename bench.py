@@ -598,15 +598,19 @@ def main():
             # config #3: inverse from the factors just checked
             LU = LU_chk
             inv = torch.empty(n, n, dtype=tdt, device="cuda")
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            dev.getri(LU, ip_chk, inv)
-            torch.cuda.synchronize()
-            t_inv = time.perf_counter() - t0
+            dev.getri(LU, ip_chk, inv)   # untimed: the first call allocates the n x n workspace
+            t_inv = float("inf")
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dev.getri(LU, ip_chk, inv)
+                torch.cuda.synchronize()
+                t_inv = min(t_inv, time.perf_counter() - t0)
             ident_err = (A_chk @ inv - torch.eye(n, dtype=tdt, device="cuda")).abs().max().item()
             out["config3_inverse"] = {"getri_ms": t_inv * 1e3, "lu_plus_inverse_ms": t_inv * 1e3 + ms_per_step,
                                       "gflops_2n3": 2.0 * n ** 3 / (t_inv + ms_per_step * 1e-3) / 1e9,
-                                      "max_abs_A_inv_minus_I": ident_err}
+                                      "max_abs_A_inv_minus_I": ident_err,
+                                      "note": "inverse from the factors (lsx_getri_f64_dev), best of 2 after one untimed call"}
     if world == 1 and not args.no_extras and args.dtype == "f64":
         # the same factorisation through the HOST-buffer entry point (lsx_getrf_f64: H2D, LU, D2H of a
         # 512 MiB matrix in pageable memory) -- never the headline value, reported beside it
