@@ -6,7 +6,7 @@ from linalg_solver_amd.device import DeviceSolver
 dev = DeviceSolver()
 OPT = sys.argv[1] if len(sys.argv) > 1 else "chain_fused"
 VALS = [int(v) for v in sys.argv[2:4]] if len(sys.argv) > 3 else [0, 1]
-for n in (8192, 4096, 6144, 12288, 16384):
+for n in (16384, 12288, 10240, 8192):
     A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
     dev.fill_(A0, gen.U11, 1)
     ref = None
