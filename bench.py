@@ -55,6 +55,27 @@ def cpu_baseline(sample_n: int):
     out = {"value": flops / dt / 1e9, "unit": "GFLOP/s", "cores": 1, "kind": "port",
            "sample": f"oracle/rowreduce_ref.c row_reduce([A|b]) at n={sample_n} u11 seed 1 "
                      f"({dt:.1f} s, n^3 flops); reference Python itself: 0.013 GFLOP/s (BASELINE.md)"}
+    # LAPACK beside it, in a CHILD process: a crash inside a BLAS thread pool (seen under torch.distributed.run, which
+    # exports OMP_NUM_THREADS=1 to its ranks) must not take the benchmark with it
+    try:
+        import subprocess
+
+        env = {k: v for k, v in os.environ.items() if k not in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS")}
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--lapack-child"], capture_output=True, text=True,
+                           timeout=240, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        out["lapack_dgetrf"] = json.loads(line[-1]) if (r.returncode == 0 and line) else \
+            {"error": f"child exit code {r.returncode}", "stderr_tail": r.stderr[-300:]}
+    except Exception as e:
+        out["lapack_dgetrf"] = {"error": str(e)}
+    return out
+
+
+def lapack_child():
+    """`bench.py --lapack-child`: LAPACK's dgetrf through scipy on the host cores, one JSON line.  No GPU, no torch."""
+    from linalg_solver_amd import gen
+
+    out = {}
     try:
         import scipy.linalg as sl
 
@@ -92,12 +113,12 @@ def cpu_baseline(sample_n: int):
                     ctx.restore_original_limits()
             results.append((lu_flops(n2) / best / 1e9, nt))
         gf, nt = max(results)
-        out["lapack_dgetrf"] = {"value": gf, "unit": "GFLOP/s", "n": n2, "threads": nt or "default", "cores_visible": cores,
+        out = {"value": gf, "unit": "GFLOP/s", "n": n2, "threads": nt or "default", "cores_visible": cores,
                                 "by_threads": {str(t): round(g, 1) for g, t in results}, "threadpools": pools,
                                 "note": "scipy.linalg.lu_factor, best of 2 per pool size after a warm-up call, every BLAS/OpenMP pool limited to `threads`"}
     except Exception as e:  # scipy is optional plumbing here
-        out["lapack_dgetrf"] = {"error": str(e)}
-    return out
+        out = {"error": str(e)}
+    print(json.dumps(out))
 
 
 def sharded_residual(torch, dist, slu, LUloc, A0loc, piv, rehearsal):
@@ -222,6 +243,8 @@ def bench_mg(args, torch):
 
 
 def main():
+    if "--lapack-child" in sys.argv:
+        return lapack_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -734,7 +757,7 @@ def main():
         res["reference_python_s"] = 12.33
         res["note"] = "reference figure measured in the build container (BASELINE.md); traced results are bit-identical to it"
         out["config1_64"] = res
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:   # (the contract: on rank 0 at N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample)
     else:
         out["cpu_baseline"] = None

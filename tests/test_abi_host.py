@@ -90,3 +90,25 @@ def test_generator_is_deterministic_and_in_range():
     assert (b == a[1:3, 2:5]).all()
     u = gen.fill(gen.U11, 9, 64, 64)
     assert (u >= -1).all() and (u < 1).all() and abs(u.mean()) < 0.1
+
+
+def test_bench_lapack_baseline_runs_in_a_child_process_and_prints_one_json_line():
+    """bench.py times LAPACK's dgetrf beside the oracle -- in a CHILD process (`bench.py --lapack-child`), because a crash in
+    a BLAS thread pool (seen on rank 0 under torch.distributed.run, which exports OMP_NUM_THREADS=1) must not take the
+    benchmark line with it; and only at N = 1.  The child needs no GPU and no torch."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OMP_NUM_THREADS="1")   # what a rank under the launcher sees; the parent strips it for the child
+    env.pop("OMP_NUM_THREADS")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--lapack-child"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert ("value" in d and d["value"] > 0 and d["n"] == 4096) or "error" in d
+    src = open(os.path.join(root, "bench.py")).read()
+    assert 'if not args.no_cpu and world == 1' in src   # the CPU baseline is rank 0's job at N = 1 only
