@@ -1061,6 +1061,33 @@ def test_panel_exchange_timeout_falls_back_to_per_column_launches(la):
     assert info2 == 0 and np.array_equal(LU2, ref[0]) and h.get_option("panel_fallbacks") == before + 2
 
 
+@pytest.mark.parametrize("n", [2560, 5000, 9216])
+def test_left_hand_interchanges_trailing_their_step_give_the_same_factors(la, dev, n):
+    """The XCD look-ahead driver applies a panel's interchanges to the columns LEFT of it behind that step's update
+    (option left_per_step, default) instead of in one launch at the end; update-bound steps with a wide left-hand side are
+    caught up later in one launch (9216: the driver starts at column 1024 behind the shared-CU phase, ragged 5000: the
+    event form of the chain).  Same interchanges in the same order on every column: same bits, same pivots."""
+    import torch
+
+    from linalg_solver_amd import gen
+
+    h = dev.h
+    A0 = torch.empty(n, n, dtype=torch.float64, device="cuda")
+    dev.fill_(A0, gen.U11, 3 + n)
+    res = []
+    try:
+        for v in (0, 1):
+            h.set_option("left_per_step", v)
+            A = A0.clone()
+            ipiv, info = dev.getrf_(A)
+            torch.cuda.synchronize()
+            res.append((A, ipiv, int(info.item())))
+    finally:
+        h.set_option("left_per_step", 1)
+    assert res[0][2] == res[1][2] == 0
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+
+
 @pytest.mark.parametrize("n,dt", [(4096, "f64"), (7200, "f64"), (4096, "f32")])
 def test_two_blocks_per_update_in_the_block_sweeps_keep_the_bits(la, dev, n, dt):
     """Inverse and many-right-hand-side solve at orders where the block substitution takes TWO 128-row blocks per
